@@ -1,0 +1,161 @@
+/*
+ * wrsn_hip.h -- C-ABI of libwrsn_hip.so, the MI355X (gfx950) implementation of the
+ * WRSN environment step path of nguyenngocbaocmt02/multi_agent_rl_wrsn.
+ *
+ * The reference exposes this path as a Python class, not an FFI:
+ *     rl_env/WRSN.py:21   class WRSN(gym.Env)
+ *     rl_env/WRSN.py:22   WRSN(scenario_path, agent_type_path, num_agent, map_size, warm_up_time, density_map)
+ *     rl_env/WRSN.py:41   reset()
+ *     rl_env/WRSN.py:289  step(agent_id, input_action)
+ * The entry points below are what a ctypes binding for a *batched* version of that class
+ * binds (INTEGRATION.md shows the stub); the Python classes `VecWRSN` / `WRSN` of
+ * multi_agent_rl_wrsn_amd are built on exactly these calls.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative wrsn_status; nothing throws
+ *     across the boundary; wrsn_last_error() returns a thread-local message;
+ *   - a handle is bound to one HIP device and one stream; calls on one handle must be
+ *     serialised by the caller, different handles are independent (one per GPU);
+ *   - pointers documented "device" are caller-owned HIP device pointers (for instance
+ *     torch.Tensor.data_ptr()); pointers documented "host" are ordinary host memory;
+ *   - the library owns only its internal environment state;
+ *   - step/reset are asynchronous on the handle's stream (no host synchronisation).
+ */
+#ifndef WRSN_HIP_H
+#define WRSN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wrsn_handle wrsn_t;
+
+enum wrsn_status {
+    WRSN_OK = 0,
+    WRSN_ERR_ARG = -1,        /* bad argument */
+    WRSN_ERR_HIP = -2,        /* HIP runtime error, see wrsn_last_error() */
+    WRSN_ERR_NO_DEVICE = -3,  /* no usable gfx950 device */
+    WRSN_ERR_CAPACITY = -4,   /* neighbour / coverage / connection list capacity exceeded */
+    WRSN_ERR_STATE = -5       /* call sequence error (e.g. step before scenario set) */
+};
+
+/* Batch geometry.  Mirrors the constructor arguments of WRSN (rl_env/WRSN.py:22-30). */
+typedef struct wrsn_cfg {
+    int32_t n_env;            /* B: number of independent environments on this handle            */
+    int32_t n_node;           /* N: sensor nodes per environment (max over the batch)            */
+    int32_t n_target;         /* T: targets per environment (max over the batch)                 */
+    int32_t n_mc;             /* M: mobile chargers, `num_agent` (WRSN.py:26); 1..8               */
+    int32_t map_size;         /* G: observation is 4 x G x G (WRSN.py:27,31)                      */
+    int32_t device;           /* HIP device ordinal                                               */
+    int32_t max_degree;       /* average neighbour-list capacity per node (0 = default 24)        */
+    int32_t max_cover;        /* average covered-target capacity per node (0 = default 8)         */
+    double  warm_up_time;     /* `warm_up_time` (WRSN.py:29,53), simulated seconds                */
+} wrsn_cfg;
+
+/* node_phy_spe of a scenario file (network_scenarios/hanoi1000n50.yaml:1-11), in this order. */
+typedef struct wrsn_node_spec {
+    double capacity, threshold, com_range, sen_range, prob_gp, package_size, er, et, efs, emp;
+    double max_time;          /* scenario key `max_time` (NetworkIO.py:34, Network.py:78)         */
+} wrsn_node_spec;
+
+/* mc_types/default.yaml:2-9 */
+typedef struct wrsn_mc_spec {
+    double capacity, threshold, velocity, pm, charging_range, alpha, beta, epsilon;
+} wrsn_mc_spec;
+
+/* Per-call outputs of reset/step: the numeric content of the request dict WRSN.step returns
+ * (WRSN.py:323-330; terminal form :313-320).  All pointers are DEVICE pointers, caller-owned;
+ * obs may be NULL (no observation is rendered). */
+typedef struct wrsn_step_out {
+    int32_t *agent_id;        /* [B]  id of the charger that needs an action; -1 = none (terminal / fell off) */
+    double  *reward;          /* [B]  get_reward (WRSN.py:222-227); 0 when agent_id < 0            */
+    uint8_t *terminal;        /* [B]  1 when net.alive == 0 at return (WRSN.py:312)                */
+    double  *now;             /* [B]  env.now at return                                            */
+    float   *obs;             /* [B,4,G,G] get_state(agent_id) (WRSN.py:130-186); untouched rows for agent_id < 0 */
+    int32_t *status;          /* [B]  0 ok; 1 step fell off the end (reference returns None);
+                                      2 every charger dead (reference would hang); 3 auto-reset performed;
+                                      negative: per-env error (capacity)                           */
+} wrsn_step_out;
+
+/* what wrsn_peek copies; dst is a HOST pointer, dense [B, ...] in the listed dtype */
+enum wrsn_peek_what {
+    WRSN_PEEK_NODE_ENERGY = 0,   /* double [B,N]   Node.energy                                   */
+    WRSN_PEEK_NODE_CS = 1,       /* double [B,N]   Node.energyCS                                  */
+    WRSN_PEEK_NODE_RR = 2,       /* double [B,N]   Node.energyRR                                  */
+    WRSN_PEEK_NODE_STATUS = 3,   /* int32  [B,N]   Node.status                                    */
+    WRSN_PEEK_NODE_LEVEL = 4,    /* int32  [B,N]   Node.level                                     */
+    WRSN_PEEK_MC = 5,            /* double [B,M,16] loc_x, loc_y, energy, status, charging, cur_x, cur_y,
+                                                    cur_t, n_conn, excl, prev_minfit, act0, act1, act2, 0, 0 */
+    WRSN_PEEK_ENV = 6,           /* double [B,16]  xmin,xmax,ymin,ymax,density,moving_time_max,charging_time_max,
+                                                    avg_nodes_agent,now,alive,ticks,exact_ticks,events,min_fitness,
+                                                    n_edges,n_cover                                 */
+    WRSN_PEEK_NODE_DEGREE = 7,   /* int32  [B,N]   len(Node.neighbors)                            */
+    WRSN_PEEK_NODE_NCOVER = 8,   /* int32  [B,N]   len(Node.listTargets)                          */
+    WRSN_PEEK_NODE_DIRECT = 9    /* int32  [B,N]   node in BaseStation.direct_nodes               */
+};
+
+/* Create a handle for B environments on cfg->device.  Fails with WRSN_ERR_NO_DEVICE when no HIP
+ * device is usable: there is no CPU fallback. */
+int wrsn_create(const wrsn_cfg *cfg, wrsn_t **out);
+void wrsn_destroy(wrsn_t *h);
+
+/* Bind the handle to a HIP stream (hipStream_t passed as void*; NULL = default stream). */
+int wrsn_set_stream(wrsn_t *h, void *hip_stream);
+
+/* Load scenarios for environments [env0, env0+nenv): replaces NetworkIO.makeNetwork
+ * (NetworkIO.py:19-34) + Network.__init__ (Network.py:4-33) + the t=0 probes
+ * (Node.py:80-90, BaseStation.py:20-23).  HOST pointers:
+ *   node_xy   [nenv, n_node, 2]   target_xy [nenv, n_target, 2]   bs_xy [nenv, 2]
+ *   n_node_env / n_target_env [nenv] actual sizes (NULL = cfg sizes for all)
+ *   node_spec [nenv] (or one spec broadcast when spec_stride == 0), mc_spec likewise.
+ * Builds topology on the device, runs the warm-up (WRSN.py:53) on the device and caches the
+ * post-warm-up snapshot reset() restores (the state after run(until=warm_up_time) is a pure
+ * function of the scenario).  Synchronous. */
+int wrsn_set_scenario(wrsn_t *h, int32_t env0, int32_t nenv,
+                      const double *node_xy, const double *target_xy, const double *bs_xy,
+                      const int32_t *n_node_env, const int32_t *n_target_env,
+                      const wrsn_node_spec *node_spec, int32_t node_spec_stride,
+                      const wrsn_mc_spec *mc_spec, int32_t mc_spec_stride);
+
+/* WRSN.reset (WRSN.py:41-83) for the environments whose env_mask byte is non-zero
+ * (DEVICE pointer [B]; NULL = all).  Outputs follow the reset request (agent 0, reward 0). */
+int wrsn_reset(wrsn_t *h, const uint8_t *env_mask, const wrsn_step_out *out);
+
+/* WRSN.step (WRSN.py:289-330) for every environment, density_map=False path.
+ *   agent_id [B] DEVICE int32: charger receiving `action` (>= 0), -1 = "just run" (WRSN.py:290),
+ *                              -2 = leave this environment untouched;
+ *   action   [B,3] DEVICE double: normalised action, clipped to [0,1] inside (WRSN.py:299).
+ * auto_reset != 0: an environment whose previous return was terminal is reset instead of stepped
+ * and reports status 3 with the reset request (agent 0, reward 0). */
+int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t auto_reset,
+              const wrsn_step_out *out);
+
+/* Render get_state(agent) for arbitrary agents (DEVICE int32 [B], < 0 = skip) into obs (DEVICE). */
+int wrsn_render(wrsn_t *h, const int32_t *agent_id, float *obs);
+
+/* Copy internal state to HOST memory (parity tests, `net` / `agents` views).  Synchronises. */
+int wrsn_peek(wrsn_t *h, int32_t what, void *dst);
+
+/* Wait for the handle's stream. */
+int wrsn_sync(wrsn_t *h);
+
+/* Cumulative device counters since create: [0] simulated node ticks, [1] exact-walk ticks,
+ * [2] events dispatched, [3] env-steps executed.  HOST pointer to 4 x int64.  Synchronises. */
+int wrsn_counters(wrsn_t *h, int64_t *dst);
+
+/* Seeded synthetic network generator (host code): fills HOST arrays
+ * node_xy [n_node,2], target_xy [n_target,2], bs_xy [2].  side <= 0 selects
+ * 1000 * max(1, sqrt(n_node / 200)) metres. */
+int wrsn_synth_network(uint64_t seed, int32_t n_node, int32_t n_target, double side,
+                       double com_range, double sen_range,
+                       double *node_xy, double *target_xy, double *bs_xy);
+
+const char *wrsn_last_error(void);
+const char *wrsn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WRSN_HIP_H */

@@ -1,0 +1,428 @@
+// wrsn_api.hip -- host side of libwrsn_hip.so: the C-ABI declared in include/wrsn_hip.h.
+// Owns device memory of a handle and launches the gfx950 kernels of wrsn_sim.h.  There is no CPU
+// execution path: without a HIP device wrsn_create fails with WRSN_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wrsn_hip.h"
+#include "wrsn_sim.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(WRSN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int npl_for(int n_node) {
+    int need = (n_node + 63) / 64;
+    const int choices[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int c : choices) if (c >= need) return c;
+    return -1;
+}
+
+}  // namespace
+
+struct wrsn_handle {
+    wrsn_cfg cfg;
+    WrsnDev dev;
+    hipStream_t stream;
+    int npl;
+    int scenario_set;
+    int lds_env, lds_obs;
+    std::vector<void*> allocs;
+    int32_t* d_agent_tmp;      // [B] agent ids for rendering when the caller passes no agent_id output
+    int32_t* d_reset_agent;    // [B] -1 everywhere: "agent" argument of a reset launch
+};
+
+namespace {
+
+template <typename T>
+int dalloc(wrsn_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes));
+    HIPCHK(hipMemset(q, 0, bytes));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+
+int alloc_node_arrays(wrsn_handle* h, WrsnNodeArrays* a) {
+    const size_t B = h->dev.B, NP = h->dev.NP;
+    int rc;
+    if ((rc = dalloc(h, &a->E, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->CS, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->RR, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->d1, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->d2, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->ring, B * WRSN_RING * NP))) return rc;
+    if ((rc = dalloc(h, &a->logbuf, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->ls, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->rcv, B * NP))) return rc;
+    if ((rc = dalloc(h, &a->conn, B * WRSN_MAX_MC * WRSN_CONN_CAP))) return rc;
+    if ((rc = dalloc(h, &a->conn_rate, B * WRSN_MAX_MC * WRSN_CONN_CAP))) return rc;
+    if ((rc = dalloc(h, &a->dyn, B))) return rc;
+    return 0;
+}
+
+int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agent_id, const double* action,
+               int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out) {
+    dim3 grid(nenv), block(64);
+    const int lds = h->lds_env;
+#define WRSN_LAUNCH(NPL_)                                                                                          \
+    hipLaunchKernelGGL(wrsn_env_kernel<NPL_>, grid, block, lds, h->stream, h->dev, mode, env0, agent_id, action, \
+                       auto_reset, mask, out)
+    switch (h->npl) {
+    case 1: WRSN_LAUNCH(1); break;
+    case 2: WRSN_LAUNCH(2); break;
+    case 3: WRSN_LAUNCH(3); break;
+    case 4: WRSN_LAUNCH(4); break;
+    case 6: WRSN_LAUNCH(6); break;
+    case 8: WRSN_LAUNCH(8); break;
+    case 12: WRSN_LAUNCH(12); break;
+    case 16: WRSN_LAUNCH(16); break;
+    default: return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane");
+    }
+#undef WRSN_LAUNCH
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int launch_obs(wrsn_handle* h, const int32_t* agent_id, float* obs) {
+    hipLaunchKernelGGL(wrsn_obs_kernel, dim3(h->dev.B), dim3(256), h->lds_obs, h->stream, h->dev, agent_id, obs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// xoshiro256** seeded by splitmix64: the synthetic generator's own counter-free RNG
+struct Rng {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t& x) {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    explicit Rng(uint64_t seed) { uint64_t x = seed; for (int i = 0; i < 4; ++i) s[i] = splitmix(x); }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    double uni(double a, double b) { return a + (b - a) * uni(); }
+    int below(int n) { return (int)(uni() * n) % (n > 0 ? n : 1); }
+    double normal() { double u1 = uni(), u2 = uni(); if (u1 < 1e-300) u1 = 1e-300; return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* wrsn_last_error(void) { return g_err.c_str(); }
+const char* wrsn_version(void) { return "wrsn_hip 0.1 (gfx950)"; }
+
+int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
+    if (!cfg || !out) return fail(WRSN_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->n_env < 1 || cfg->n_node < 1 || cfg->n_target < 1 || cfg->n_mc < 1 || cfg->n_mc > WRSN_MAX_MC || cfg->map_size < 4 ||
+        cfg->map_size > 256 || cfg->n_node > 1024 || !(cfg->warm_up_time > 0.0))
+        return fail(WRSN_ERR_ARG, "wrsn_cfg out of range (n_mc 1..8, n_node 1..1024, map_size 4..256, warm_up_time > 0)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(WRSN_ERR_NO_DEVICE, "no HIP device: libwrsn_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(WRSN_ERR_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+    wrsn_handle* h = new wrsn_handle();
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0;
+    h->npl = npl_for(cfg->n_node);
+    if (h->npl < 0) { delete h; return fail(WRSN_ERR_ARG, "n_node too large"); }
+    WrsnDev& d = h->dev;
+    std::memset(&d, 0, sizeof(d));
+    d.B = cfg->n_env; d.N = cfg->n_node; d.T = cfg->n_target; d.M = cfg->n_mc; d.G = cfg->map_size;
+    d.NP = h->npl * 64; d.TP = ((cfg->n_target + 63) / 64) * 64;
+    d.ECAP = (cfg->max_degree > 0 ? cfg->max_degree : 24) * d.NP;
+    d.CCAP = (cfg->max_cover > 0 ? cfg->max_cover : 8) * d.NP;
+    // observation tile geometry must fit the register tile of wrsn_obs_kernel
+    {
+        int CG = (d.G + 3) / 4; int RG = 256 / CG; if (RG < 1) { delete h; return fail(WRSN_ERR_ARG, "map_size too large"); }
+        int RPG = (d.G + RG - 1) / RG; if (RPG > WRSN_OBS_MAXROWS) { delete h; return fail(WRSN_ERR_ARG, "map_size too large for the observation tile"); }
+    }
+    h->lds_env = wrsn_lds_bytes(d.NP, d.M);
+    h->lds_obs = wrsn_obs_lds_bytes(d.G);
+    const size_t B = d.B, NP = d.NP;
+    int rc = 0;
+    do {
+        if ((rc = dalloc(h, &d.ec, B))) break;
+        if ((rc = dalloc(h, &d.node_x, B * NP))) break;
+        if ((rc = dalloc(h, &d.node_y, B * NP))) break;
+        if ((rc = dalloc(h, &d.dist_bs, B * NP))) break;
+        if ((rc = dalloc(h, &d.target_x, B * d.TP))) break;
+        if ((rc = dalloc(h, &d.target_y, B * d.TP))) break;
+        if ((rc = dalloc(h, &d.nb_off, B * (NP + 1)))) break;
+        if ((rc = dalloc(h, &d.nb_idx, B * (size_t)d.ECAP))) break;
+        if ((rc = dalloc(h, &d.nb_dist, B * (size_t)d.ECAP))) break;
+        if ((rc = dalloc(h, &d.tc_off, B * (size_t)(d.TP + 1)))) break;
+        if ((rc = dalloc(h, &d.tc_idx, B * (size_t)d.CCAP))) break;
+        if ((rc = dalloc(h, &d.ncov, B * NP))) break;
+        if ((rc = dalloc(h, &d.nflags, B * NP))) break;
+        if ((rc = alloc_node_arrays(h, &d.live))) break;
+        if ((rc = alloc_node_arrays(h, &d.snap))) break;
+        if ((rc = dalloc(h, &d.counters, 4))) break;
+        if ((rc = dalloc(h, &h->d_agent_tmp, B))) break;
+        if ((rc = dalloc(h, &h->d_reset_agent, B))) break;
+    } while (0);
+    if (rc) { wrsn_destroy(h); return rc; }
+    {
+        std::vector<int32_t> neg(B, -1);
+        if (hipMemcpy(h->d_reset_agent, neg.data(), B * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
+    }
+    *out = h;
+    return WRSN_OK;
+}
+
+void wrsn_destroy(wrsn_t* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int wrsn_set_stream(wrsn_t* h, void* hip_stream) {
+    if (!h) return fail(WRSN_ERR_ARG, "null handle");
+    h->stream = (hipStream_t)hip_stream;
+    return WRSN_OK;
+}
+
+int wrsn_set_scenario(wrsn_t* h, int32_t env0, int32_t nenv, const double* node_xy, const double* target_xy,
+                      const double* bs_xy, const int32_t* n_node_env, const int32_t* n_target_env,
+                      const wrsn_node_spec* node_spec, int32_t node_spec_stride, const wrsn_mc_spec* mc_spec,
+                      int32_t mc_spec_stride) {
+    if (!h || !node_xy || !target_xy || !bs_xy || !node_spec || !mc_spec) return fail(WRSN_ERR_ARG, "null argument");
+    const WrsnDev& d = h->dev;
+    if (env0 < 0 || nenv < 1 || env0 + nenv > d.B) return fail(WRSN_ERR_ARG, "environment range out of bounds");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t NP = d.NP, TP = d.TP;
+    std::vector<double> hx(nenv * NP, 0.0), hy(nenv * NP, 0.0), tx(nenv * TP, 0.0), ty(nenv * TP, 0.0);
+    std::vector<WrsnEnvConst> ec(nenv);
+    for (int e = 0; e < nenv; ++e) {
+        const int n = n_node_env ? n_node_env[e] : d.N, t = n_target_env ? n_target_env[e] : d.T;
+        if (n < 1 || n > d.N || t < 1 || t > d.T) return fail(WRSN_ERR_ARG, "per-environment node/target count out of range");
+        const wrsn_node_spec& ns = node_spec[(size_t)e * (node_spec_stride ? 1 : 0)];
+        const wrsn_mc_spec& ms = mc_spec[(size_t)e * (mc_spec_stride ? 1 : 0)];
+        if (ns.prob_gp != 1.0) return fail(WRSN_ERR_ARG, "prob_gp != 1 is not supported (Node.py:61 draws Python's MT19937)");
+        for (int i = 0; i < n; ++i) { hx[e * NP + i] = node_xy[((size_t)e * d.N + i) * 2]; hy[e * NP + i] = node_xy[((size_t)e * d.N + i) * 2 + 1]; }
+        for (int i = 0; i < t; ++i) { tx[e * TP + i] = target_xy[((size_t)e * d.T + i) * 2]; ty[e * TP + i] = target_xy[((size_t)e * d.T + i) * 2 + 1]; }
+        WrsnEnvConst& c = ec[e];
+        std::memset(&c, 0, sizeof(c));
+        c.capacity = ns.capacity; c.threshold = ns.threshold; c.com_range = ns.com_range; c.sen_range = ns.sen_range;
+        c.package_size = ns.package_size; c.er = ns.er; c.et = ns.et; c.efs = ns.efs; c.emp = ns.emp; c.max_time = ns.max_time;
+        c.mc_capacity = ms.capacity; c.mc_threshold = ms.threshold; c.velocity = ms.velocity; c.pm = ms.pm;
+        c.charging_range = ms.charging_range; c.alpha = ms.alpha; c.beta = ms.beta; c.epsilon = ms.epsilon;
+        c.bs[0] = bs_xy[e * 2]; c.bs[1] = bs_xy[e * 2 + 1];
+        c.warm_up_time = h->cfg.warm_up_time;
+        c.n_node = n; c.n_target = t;
+    }
+    HIPCHK(hipMemcpy(d.node_x + (size_t)env0 * NP, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.node_y + (size_t)env0 * NP, hy.data(), hy.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.target_x + (size_t)env0 * TP, tx.data(), tx.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.target_y + (size_t)env0 * TP, ty.data(), ty.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.ec + env0, ec.data(), ec.size() * sizeof(WrsnEnvConst), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(wrsn_topology_kernel, dim3(nenv), dim3(64), 0, h->stream, h->dev, env0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(ec.data(), d.ec + env0, ec.size() * sizeof(WrsnEnvConst), hipMemcpyDeviceToHost));
+    for (int e = 0; e < nenv; ++e) {
+        if (ec[e].error == -1) return fail(WRSN_ERR_CAPACITY, "neighbour list capacity exceeded (raise wrsn_cfg.max_degree); env " + std::to_string(env0 + e) + " has " + std::to_string(ec[e].n_edges) + " directed edges");
+        if (ec[e].error == -2) return fail(WRSN_ERR_CAPACITY, "coverage list capacity exceeded (raise wrsn_cfg.max_cover); env " + std::to_string(env0 + e));
+    }
+    WrsnStepOutDev none; std::memset(&none, 0, sizeof(none));
+    int rc = launch_env(h, WRSN_MODE_WARMUP, env0, nenv, nullptr, nullptr, 0, nullptr, none);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->scenario_set = 1;
+    return WRSN_OK;
+}
+
+int wrsn_reset(wrsn_t* h, const uint8_t* env_mask, const wrsn_step_out* out) {
+    if (!h || !out) return fail(WRSN_ERR_ARG, "null argument");
+    if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    WrsnStepOutDev o; o.agent_id = out->agent_id ? out->agent_id : h->d_agent_tmp; o.reward = out->reward; o.terminal = out->terminal;
+    o.now = out->now; o.obs = out->obs; o.status = out->status;
+    if (env_mask && out->obs) {
+        // rows of unmasked environments must not be rendered: mark them with agent -1 first
+        HIPCHK(hipMemcpyAsync(o.agent_id, h->d_reset_agent, (size_t)h->dev.B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    }
+    int rc = launch_env(h, WRSN_MODE_RESET, 0, h->dev.B, nullptr, nullptr, 0, env_mask, o);
+    if (rc) return rc;
+    if (out->obs) return launch_obs(h, o.agent_id, out->obs);
+    return WRSN_OK;
+}
+
+int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t auto_reset, const wrsn_step_out* out) {
+    if (!h || !out || !agent_id || !action) return fail(WRSN_ERR_ARG, "null argument");
+    if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    WrsnStepOutDev o; o.agent_id = out->agent_id ? out->agent_id : h->d_agent_tmp; o.reward = out->reward; o.terminal = out->terminal;
+    o.now = out->now; o.obs = out->obs; o.status = out->status;
+    if (out->obs) HIPCHK(hipMemcpyAsync(o.agent_id, h->d_reset_agent, (size_t)h->dev.B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    int rc = launch_env(h, WRSN_MODE_STEP, 0, h->dev.B, agent_id, action, auto_reset, nullptr, o);
+    if (rc) return rc;
+    if (out->obs) return launch_obs(h, o.agent_id, out->obs);
+    return WRSN_OK;
+}
+
+int wrsn_render(wrsn_t* h, const int32_t* agent_id, float* obs) {
+    if (!h || !agent_id || !obs) return fail(WRSN_ERR_ARG, "null argument");
+    if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    return launch_obs(h, agent_id, obs);
+}
+
+int wrsn_sync(wrsn_t* h) {
+    if (!h) return fail(WRSN_ERR_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return WRSN_OK;
+}
+
+int wrsn_peek(wrsn_t* h, int32_t what, void* dst) {
+    if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
+    const WrsnDev& d = h->dev;
+    const size_t B = d.B, NP = d.NP, N = d.N;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto node_f64 = [&](const double* src) -> int {
+        std::vector<double> tmp(B * NP);
+        HIPCHK(hipMemcpy(tmp.data(), src, tmp.size() * 8, hipMemcpyDeviceToHost));
+        double* o = (double*)dst;
+        for (size_t e = 0; e < B; ++e) for (size_t i = 0; i < N; ++i) o[e * N + i] = tmp[e * NP + i];
+        return 0;
+    };
+    auto node_i32 = [&](const int32_t* src, int mode) -> int {
+        std::vector<int32_t> tmp(B * NP);
+        HIPCHK(hipMemcpy(tmp.data(), src, tmp.size() * 4, hipMemcpyDeviceToHost));
+        int32_t* o = (int32_t*)dst;
+        for (size_t e = 0; e < B; ++e)
+            for (size_t i = 0; i < N; ++i) {
+                int32_t v = tmp[e * NP + i];
+                o[e * N + i] = mode == 0 ? v : (mode == 1 ? (v & 1) : ((v >> 1) - 1));
+            }
+        return 0;
+    };
+    switch (what) {
+    case WRSN_PEEK_NODE_ENERGY: return node_f64(d.live.E);
+    case WRSN_PEEK_NODE_CS: return node_f64(d.live.CS);
+    case WRSN_PEEK_NODE_RR: return node_f64(d.live.RR);
+    case WRSN_PEEK_NODE_STATUS: return node_i32(d.live.ls, 1);
+    case WRSN_PEEK_NODE_LEVEL: return node_i32(d.live.ls, 2);
+    case WRSN_PEEK_NODE_NCOVER: return node_i32(d.ncov, 0);
+    case WRSN_PEEK_NODE_DIRECT: return node_i32(d.nflags, 1);
+    case WRSN_PEEK_NODE_DEGREE: {
+        std::vector<int32_t> tmp(B * (NP + 1));
+        HIPCHK(hipMemcpy(tmp.data(), d.nb_off, tmp.size() * 4, hipMemcpyDeviceToHost));
+        int32_t* o = (int32_t*)dst;
+        for (size_t e = 0; e < B; ++e) for (size_t i = 0; i < N; ++i) o[e * N + i] = tmp[e * (NP + 1) + i + 1] - tmp[e * (NP + 1) + i];
+        return 0; }
+    case WRSN_PEEK_MC: {
+        std::vector<WrsnEnvDyn> dy(B);
+        HIPCHK(hipMemcpy(dy.data(), d.live.dyn, B * sizeof(WrsnEnvDyn), hipMemcpyDeviceToHost));
+        double* o = (double*)dst;
+        for (size_t e = 0; e < B; ++e)
+            for (int m = 0; m < d.M; ++m) {
+                const WrsnAgent& a = dy[e].ag[m]; double* q = o + (e * d.M + m) * 16;
+                q[0] = a.loc[0]; q[1] = a.loc[1]; q[2] = a.energy; q[3] = a.status; q[4] = a.type_charging;
+                q[5] = a.cur[0]; q[6] = a.cur[1]; q[7] = a.cur[2]; q[8] = a.n_conn; q[9] = a.excl; q[10] = a.prev_minfit;
+                q[11] = a.action[0]; q[12] = a.action[1]; q[13] = a.action[2]; q[14] = 0; q[15] = 0;
+            }
+        return 0; }
+    case WRSN_PEEK_ENV: {
+        std::vector<WrsnEnvDyn> dy(B); std::vector<WrsnEnvConst> ec(B);
+        HIPCHK(hipMemcpy(dy.data(), d.live.dyn, B * sizeof(WrsnEnvDyn), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ec.data(), d.ec, B * sizeof(WrsnEnvConst), hipMemcpyDeviceToHost));
+        double* o = (double*)dst;
+        for (size_t e = 0; e < B; ++e) {
+            double* q = o + e * 16;
+            q[0] = ec[e].frame[0]; q[1] = ec[e].frame[1]; q[2] = ec[e].frame[2]; q[3] = ec[e].frame[3];
+            q[4] = ec[e].density; q[5] = ec[e].moving_time_max; q[6] = ec[e].charging_time_max; q[7] = ec[e].avg_nodes_agent;
+            q[8] = dy[e].now; q[9] = dy[e].alive; q[10] = (double)dy[e].n_ticks; q[11] = (double)dy[e].n_exact;
+            q[12] = (double)dy[e].n_events; q[13] = dy[e].last_minfit; q[14] = ec[e].n_edges; q[15] = ec[e].n_cover;
+        }
+        return 0; }
+    default: return fail(WRSN_ERR_ARG, "unknown peek selector");
+    }
+}
+
+int wrsn_counters(wrsn_t* h, int64_t* dst) {
+    if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
+    const size_t B = h->dev.B;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<WrsnEnvDyn> dy(B);
+    HIPCHK(hipMemcpy(dy.data(), h->dev.live.dyn, B * sizeof(WrsnEnvDyn), hipMemcpyDeviceToHost));
+    // n_ticks / n_exact / n_events restart at every reset (they live in the snapshot); n_steps is cumulative
+    dst[0] = dst[1] = dst[2] = dst[3] = 0;
+    for (size_t e = 0; e < B; ++e) { dst[0] += dy[e].n_ticks; dst[1] += dy[e].n_exact; dst[2] += dy[e].n_events; dst[3] += dy[e].n_steps; }
+    return WRSN_OK;
+}
+
+int wrsn_synth_network(uint64_t seed, int32_t n_node, int32_t n_target, double side, double com_range,
+                       double sen_range, double* node_xy, double* target_xy, double* bs_xy) {
+    if (n_node < 2 || n_target < 1 || !node_xy || !target_xy || !bs_xy || !(com_range > 0) || !(sen_range > 0))
+        return fail(WRSN_ERR_ARG, "bad generator argument");
+    if (side <= 0) side = 1000.0 * std::fmax(1.0, std::sqrt(n_node / 200.0));
+    Rng rng(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull);
+    const double com = com_range, sen = sen_range;
+    const double bx = side / 2, by = side / 2;
+    const double hop_lo = 0.62 * com, hop_hi = 0.995 * com, min_sep = 0.56 * com;
+    std::vector<int> tips;
+    int n = 0, n_direct = 2 + rng.below(3);
+    long tries = 0;
+    while (n < n_node) {
+        if (++tries > 4000000L) return fail(WRSN_ERR_ARG, "synthetic generator could not place the nodes (field too small?)");
+        double px, py; int par = -1;
+        if (n < n_direct) {
+            double ang = rng.uni(0, 6.283185307179586), r = rng.uni(0.35 * com, 0.95 * com);
+            px = bx + r * std::cos(ang); py = by + r * std::sin(ang);
+        } else {
+            if (!tips.empty() && rng.uni() < 0.93) par = tips[rng.below((int)tips.size())];
+            else par = rng.below(n);
+            double ox = node_xy[2 * par] - bx, oy = node_xy[2 * par + 1] - by;
+            double ang = std::atan2(oy, ox) + 0.75 * rng.normal(), r = rng.uni(hop_lo, hop_hi);
+            px = node_xy[2 * par] + r * std::cos(ang); py = node_xy[2 * par + 1] + r * std::sin(ang);
+        }
+        if (px < 0 || px > side || py < 0 || py > side) continue;
+        bool ok = true;
+        for (int k = 0; k < n && ok; ++k) { double dx = node_xy[2 * k] - px, dy = node_xy[2 * k + 1] - py; if (dx * dx + dy * dy < min_sep * min_sep) ok = false; }
+        if (!ok) continue;
+        node_xy[2 * n] = px; node_xy[2 * n + 1] = py;
+        for (size_t k = 0; k < tips.size(); ++k) if (tips[k] == par) { tips.erase(tips.begin() + k); break; }
+        tips.push_back(n);
+        if (tips.size() > 24) tips.erase(tips.begin());
+        ++n;
+    }
+    // targets: inside 0.93 * sensing range of an owner node, biased towards the outer nodes
+    std::vector<double> cum(n_node);
+    double dmax = 0; for (int i = 0; i < n_node; ++i) dmax = std::fmax(dmax, std::hypot(node_xy[2 * i] - bx, node_xy[2 * i + 1] - by));
+    double acc = 0; for (int i = 0; i < n_node; ++i) { acc += 0.25 + std::hypot(node_xy[2 * i] - bx, node_xy[2 * i + 1] - by) / dmax; cum[i] = acc; }
+    for (int t = 0; t < n_target; ++t) {
+        double u = rng.uni() * acc; int lo = 0, hi = n_node - 1;
+        while (lo < hi) { int mid = (lo + hi) / 2; if (cum[mid] < u) lo = mid + 1; else hi = mid; }
+        double ang = rng.uni(0, 6.283185307179586), r = 0.93 * sen * std::sqrt(rng.uni());
+        target_xy[2 * t] = node_xy[2 * lo] + r * std::cos(ang); target_xy[2 * t + 1] = node_xy[2 * lo + 1] + r * std::sin(ang);
+    }
+    bs_xy[0] = bx; bs_xy[1] = by;
+    return WRSN_OK;
+}
+
+}  // extern "C"

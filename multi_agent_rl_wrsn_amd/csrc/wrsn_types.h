@@ -1,0 +1,104 @@
+// wrsn_types.h -- plain structs shared by the host C-ABI layer and the gfx950 kernels.
+// Names follow the reference's domain (nodes, targets, mobile chargers, base station).
+#pragma once
+#include <stdint.h>
+
+#define WRSN_WAVE 64
+#define WRSN_MAX_MC 8                    // mobile chargers per environment
+#define WRSN_MAX_TH (2 * WRSN_MAX_MC)    // operate_step processes alive at once (current + superseded)
+#define WRSN_CONN_CAP 32                 // nodes inside one charger's charging range
+#define WRSN_RING 10                     // Node.log window (Node.py:71-77)
+
+// run modes of the environment kernel
+#define WRSN_MODE_STEP 0
+#define WRSN_MODE_WARMUP 1
+#define WRSN_MODE_RESET 2
+
+// per-environment constants: scenario + charger parameters and what Network.__init__ /
+// WRSN.reset derive from them (Network.py:16-27, WRSN.py:50-52)
+struct WrsnEnvConst {
+    double capacity, threshold, com_range, sen_range, package_size, er, et, efs, emp, max_time;
+    double mc_capacity, mc_threshold, velocity, pm, charging_range, alpha, beta, epsilon;
+    double bs[2], frame[4], density, moving_time_max, charging_time_max, avg_nodes_agent;
+    double e_recv, d0, warm_up_time;
+    int32_t n_node, n_target, n_edges, n_cover, error, pad;
+};
+
+// MobileCharger object state (MobileCharger.py:6-32) + the per-agent lists WRSN keeps (WRSN.py:33-38)
+struct WrsnAgent {
+    double loc[2], energy, charging_rate, cur[3];   // location, energy, chargingRate, cur_phy_action
+    double prev_minfit, excl, action[3];            // min(agents_prev_fitness), agents_exclusive_reward, agents_action
+    double conn_loc[2];                             // charger location the cached connection rates were computed for
+    int32_t status, type_charging, n_conn, cur_thread;
+    int32_t n_live, pad;                            // connections made by the running charge sub-step
+};
+
+// one operate_step process tree (MobileCharger.py:105-132): its single pending event + generator locals
+struct WrsnThread {
+    double time; int64_t seq;
+    double phy[3];
+    double m_dest[2], moving_time, mvec[2], total_time, span;   // move() locals
+    double tmp, cspan;                                          // charge() locals
+    int32_t pc, agent, prio, stage;
+};
+
+// everything else that persists between two step() calls of one environment
+struct WrsnEnvDyn {
+    double now; int64_t seq;
+    double net_time; int64_t net_seq;        // Network.operate pending timeout
+    double ur_time; int64_t ur_seq;          // WRSN.update_reward pending timeout
+    double node_time; int64_t node_seq;      // the block of Node.operate timeouts
+    double last_minfit, opmax;
+    int64_t n_ticks, n_exact, n_events, n_steps;
+    int32_t net_phase, net_active, node_phase, alive;
+    int32_t levels_dirty, cache_dirty, irreg, ring_len;
+    int32_t ring_head, safe_ticks, frozen, terminal_pending;
+    int32_t n_connected, error, log_pending, pad1;
+    WrsnAgent ag[WRSN_MAX_MC];
+    WrsnThread th[WRSN_MAX_TH];
+};
+
+// device memory of one handle (all arrays dense over the B environments)
+struct WrsnNodeArrays {
+    double *E, *CS, *RR, *d1, *d2;    // [B][NP]   energy, energyCS, energyRR, cached per-tick drain before / after the own half-charge
+    double *ring;                     // [B][10][NP] Node.log window
+    double *logbuf;                   // [B][NP]   Node.log_energy of a second whose k+0.5 half ran the exact walk
+    int32_t *ls;                      // [B][NP]   ((level + 1) << 1) | alive
+    int32_t *rcv;                     // [B][NP]   cached receiver: node id, -2 base station, -1 none
+    int16_t *conn;                    // [B][MAX_MC][CONN_CAP] connected_nodes of each charger
+    double *conn_rate;                // [B][MAX_MC][CONN_CAP] alpha / (dist + beta)^2 at conn_loc
+    WrsnEnvDyn *dyn;                  // [B]
+};
+
+struct WrsnDev {
+    int32_t B, N, T, M, G, NP, TP, ECAP, CCAP, pad;
+    WrsnEnvConst *ec;                 // [B]
+    double *node_x, *node_y, *dist_bs;   // [B][NP]
+    double *target_x, *target_y;      // [B][TP]
+    int32_t *nb_off, *nb_idx;         // [B][NP+1], [B][ECAP]  Node.neighbors (id order)
+    double *nb_dist;                  // [B][ECAP]
+    int32_t *tc_off, *tc_idx;         // [B][TP+1], [B][CCAP]  target -> covering nodes (id order)
+    int32_t *ncov, *nflags;           // [B][NP]  len(listTargets); bit0: in BaseStation.direct_nodes
+    WrsnNodeArrays live, snap;        // current state / post-warm-up snapshot
+    int64_t *counters;                // [4]
+};
+
+struct WrsnStepOutDev {
+    int32_t *agent_id; double *reward; uint8_t *terminal; double *now; float *obs; int32_t *status;
+};
+
+static inline int wrsn_lds_bytes(int NP, int M) {
+    int b = 0;
+    b += NP * 8;                 // sRR
+    b += 2 * NP * 8;             // scratch (two double arrays / two int arrays)
+    b += NP * 4 * 2;             // sLS, sRcv
+    b += M * (int)sizeof(WrsnAgent);
+    b += 2 * M * (int)sizeof(WrsnThread);
+    b += (M + 1) * (8 + 8 + 4 + 4 + 4);
+    b = (b + 7) & ~7;
+    b += M * WRSN_CONN_CAP * 8;  // cached connection rates
+    b += M * WRSN_CONN_CAP * 2;  // connected-node ids
+    b = (b + 7) & ~7;
+    b += 8 * 8;                  // service request mailbox
+    return (b + 15) & ~15;
+}

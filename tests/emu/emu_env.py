@@ -1,0 +1,59 @@
+"""TEST INFRASTRUCTURE ONLY -- drive the CPU-emulated build of the product kernels (tests/emu/libwrsn_emu.so)
+through the same C-ABI binding the product uses, with numpy arrays standing in for device memory."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from multi_agent_rl_wrsn_amd import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_EMU = None
+
+
+def emu_lib():
+    global _EMU
+    if _EMU is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libwrsn_emu.so"])
+        _EMU = _lib.bind(C.CDLL(os.path.join(_HERE, "libwrsn_emu.so")))
+    return _EMU
+
+
+class EmuVec:
+    """B environments on the emulated library; mirrors what VecWRSN does with torch tensors."""
+
+    def __init__(self, scenarios, mc_spec, num_agent, map_size=100, warm_up_time=100.0, max_degree=0, max_cover=0):
+        self.B = len(scenarios)
+        self.N = max(s.n_node for s in scenarios); self.T = max(s.n_target for s in scenarios)
+        self.M, self.G = num_agent, map_size
+        self.h = _lib.RawHandle(emu_lib(), self.B, self.N, self.T, num_agent, map_size, warm_up_time, 0, max_degree, max_cover)
+        self.h.set_scenarios(scenarios, mc_spec)
+        B, G = self.B, self.G
+        self.agent_id = np.full(B, -1, dtype=np.int32); self.reward = np.zeros(B); self.terminal = np.zeros(B, dtype=np.uint8)
+        self.now = np.zeros(B); self.status = np.zeros(B, dtype=np.int32); self.obs = np.zeros((B, 4, G, G), dtype=np.float32)
+
+    def _ptrs(self, with_obs):
+        return dict(agent_id=self.agent_id.ctypes.data, reward=self.reward.ctypes.data, terminal=self.terminal.ctypes.data,
+                    now=self.now.ctypes.data, status=self.status.ctypes.data, obs=(self.obs.ctypes.data if with_obs else 0))
+
+    def reset(self, with_obs=True):
+        self.h.reset(0, **self._ptrs(with_obs))
+        return self
+
+    def step(self, agent_ids, actions, with_obs=True, auto_reset=False):
+        a = np.ascontiguousarray(agent_ids, dtype=np.int32); act = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.B, 3)
+        self.h.step(a.ctypes.data, act.ctypes.data, auto_reset, **self._ptrs(with_obs))
+        return self
+
+    def nodes(self):
+        return {"energy": self.h.peek(_lib.PEEK_NODE_ENERGY), "cs": self.h.peek(_lib.PEEK_NODE_CS), "rr": self.h.peek(_lib.PEEK_NODE_RR),
+                "status": self.h.peek(_lib.PEEK_NODE_STATUS), "level": self.h.peek(_lib.PEEK_NODE_LEVEL)}
+
+    def mcs(self):
+        a = self.h.peek(_lib.PEEK_MC)
+        return {k: a[:, :, i].copy() for i, k in enumerate(_lib.MC_FIELDS)}
+
+    def env_info(self):
+        a = self.h.peek(_lib.PEEK_ENV)
+        return {k: a[:, i].copy() for i, k in enumerate(_lib.ENV_FIELDS)}

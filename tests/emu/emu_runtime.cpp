@@ -1,0 +1,89 @@
+// TEST INFRASTRUCTURE ONLY -- fiber scheduler of the lockstep wavefront emulator (see include/hip/hip_runtime.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+emu_idx threadIdx, blockIdx, blockDim, gridDim;
+alignas(16) double smem[160 * 1024 / 8];
+unsigned char emu_slots[2][256][16];
+int emu_parity = 0;
+
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+constexpr unsigned kMaxThreads = 256;
+void* g_main_sp;
+void* g_fiber_sp[kMaxThreads];
+std::vector<char> g_stacks;
+const std::function<void()>* g_body;
+bool g_done[kMaxThreads];
+bool g_waiting[kMaxThreads];
+unsigned g_cur;
+
+void fiber_entry() {
+    (*g_body)();
+    g_done[g_cur] = true;
+    emu_switch(&g_fiber_sp[g_cur], g_main_sp);
+    std::abort();
+}
+}  // namespace
+
+void emu_barrier() {
+    g_waiting[g_cur] = true;
+    unsigned me = g_cur;
+    emu_switch(&g_fiber_sp[me], g_main_sp);      // resumed once every live fiber has arrived
+    threadIdx.x = me;
+}
+
+void emu_run_block(const std::function<void()>& body, unsigned nthreads) {
+    if (nthreads > kMaxThreads) std::abort();
+    if (g_stacks.size() < kStack * kMaxThreads) g_stacks.resize(kStack * kMaxThreads);
+    g_body = &body;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        char* top = g_stacks.data() + kStack * (t + 1);
+        top = (char*)((uintptr_t)top & ~(uintptr_t)15);
+        void** sp = (void**)top;
+        *--sp = nullptr;                          // fake return address: entry sees rsp % 16 == 8
+        *--sp = (void*)&fiber_entry;
+        for (int i = 0; i < 6; ++i) *--sp = nullptr;
+        g_fiber_sp[t] = sp;
+        g_done[t] = false; g_waiting[t] = false;
+    }
+    for (;;) {
+        unsigned live = 0, waiting = 0;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            if (g_done[t]) continue;
+            g_cur = t; threadIdx.x = t;
+            g_waiting[t] = false;
+            emu_switch(&g_main_sp, g_fiber_sp[t]);
+            if (!g_done[t]) { ++live; if (g_waiting[t]) ++waiting; }
+        }
+        if (live == 0) break;
+        if (waiting != live) { std::fprintf(stderr, "emu: divergent rendezvous (%u of %u fibers waiting)\n", waiting, live); std::abort(); }
+        emu_parity ^= 1;
+    }
+}

@@ -1,0 +1,88 @@
+// TEST INFRASTRUCTURE ONLY -- lockstep wavefront emulator.
+//
+// Lets the *unmodified* product sources (csrc/wrsn_api.hip + csrc/wrsn_sim.h) be compiled by g++ and
+// executed on the CPU so the kernel logic can be checked against the oracle in `-m "not gpu"` tests.
+// It is not a backend: the product library (libwrsn_hip.so, built by hipcc for gfx950) never sees this
+// header, and nothing in the product package can load the emulated library.
+//
+// Model: the threads of one workgroup are fibers on one OS thread, run round-robin; every
+// collective (__syncthreads, __shfl*, __ballot) is a rendezvous of all fibers of the block, so
+// wave-uniform code behaves as on the 64-lane hardware wavefront.  Blocks run one after another.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct emu_idx { unsigned x, y, z; };
+extern emu_idx threadIdx, blockIdx, blockDim, gridDim;
+extern double smem[];                        // dynamic LDS of the running block
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0, hipErrorUnknown = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorUnknown; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+
+// ---- rendezvous primitives implemented in emu_runtime.cpp
+void emu_barrier();
+extern unsigned char emu_slots[2][256][16];
+extern int emu_parity;
+void emu_run_block(const std::function<void()>& body, unsigned nthreads);
+
+inline void __syncthreads() { emu_barrier(); }
+
+template <typename T>
+inline T emu_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 16, "shuffle payload");
+    const int p = emu_parity;                // same value in every fiber between two rendezvous
+    std::memcpy(emu_slots[p][threadIdx.x], &v, sizeof(T));
+    emu_barrier();                           // flips emu_parity once all lanes have arrived
+    T r;
+    std::memcpy(&r, emu_slots[p][src_lane & 63], sizeof(T));
+    return r;
+}
+template <typename T> inline T __shfl(T v, int src) { return emu_exchange(v, src); }
+template <typename T> inline T __shfl_xor(T v, int mask) { return emu_exchange(v, (int)threadIdx.x ^ mask); }
+template <typename T> inline T __shfl_up(T v, int delta) { int s = (int)threadIdx.x - delta; return emu_exchange(v, s < 0 ? (int)threadIdx.x : s); }
+inline unsigned long long __ballot(int pred) {
+    const int p = emu_parity;
+    unsigned char b = pred ? 1 : 0;
+    emu_slots[p][threadIdx.x][0] = b;
+    emu_barrier();
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < blockDim.x && l < 64; ++l) if (emu_slots[p][l][0]) m |= 1ull << l;
+    return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline float __expf(float x) { return expf(x); }
+
+template <typename K, typename... A>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*lds*/, hipStream_t, A... args) {
+    gridDim.x = grid.x; blockDim.x = block.x;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        blockIdx.x = b;
+        emu_run_block([&]() { kernel(args...); }, block.x);
+    }
+}
