@@ -1,0 +1,188 @@
+"""bench.py -- env-steps/s of the WRSN environment step path on N MI355X (one process per GPU).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): 4096 independent environments per GPU x 200 nodes x 200 targets x 3 mobile
+chargers, seeded synthetic networks, random policy actions ~U[0,1)^3, auto-reset on terminal.
+A "step" is one VecWRSN.step over the whole batch = one WRSN.step() per environment (plus its 4x100x100
+observation); environments that were terminal are reset instead and are NOT counted as env-steps.
+Environments are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is
+one all-gather of the rollout returns table after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def algorithmic_bytes(N, T, M, G):
+    """compulsory HBM bytes per env-step with state resident on chip during the step."""
+    physics = 112 * N + 8 * T + 104 * M + 28
+    obs = 16 * G * G
+    return physics, obs
+
+
+def cpu_baseline(scenarios, M, seconds, threads):
+    """The oracle (plain-C float64 restatement of the reference, oracle/) timed on the host cores: a bounded sample of
+    the same workload (same networks, same action distribution), one environment per thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC
+    from wrsn_oracle import OracleWRSN, lib
+    lib()
+    deadline = time.time() + seconds
+
+    def work(i):
+        s = scenarios[i % len(scenarios)]
+        o = OracleWRSN(s.node_xy, s.target_xy, s.bs_xy, s.node_spec, DEFAULT_MC_SPEC, s.max_time, M)
+        rng = np.random.RandomState(i)
+        r = o.reset(with_state=True)
+        n = 0
+        while time.time() < deadline:
+            if r["terminal"]:
+                r = o.reset(with_state=True)
+                continue
+            r = o.step(r["agent_id"], rng.rand(3), with_state=True)     # includes get_state, like WRSN.step
+            n += 1
+        return n
+
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        counts = list(ex.map(work, range(threads)))
+    dt = time.time() - t0
+    return sum(counts) / dt, sum(counts), dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--nodes", type=int, default=200)
+    ap.add_argument("--targets", type=int, default=200)
+    ap.add_argument("--mcs", type=int, default=3)
+    ap.add_argument("--map-size", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--kernel-steps", type=int, default=20, help="steps of the per-kernel timing pass")
+    args = ap.parse_args()
+
+    import torch
+    from multi_agent_rl_wrsn_amd import RolloutStats, VecWRSN, init_distributed, synth_scenario
+    rank, world, local_rank = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = torch.distributed if world > 1 else None
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, N, T, M, G = args.envs, args.nodes, args.targets, args.mcs, args.map_size
+    t_gen = time.time()
+    env0 = rank * B                                            # global environment ids of this shard
+    scenarios = [synth_scenario(args.seed + env0 + e, N, T) for e in range(B)]
+    t_gen = time.time() - t_gen
+    t_set = time.time()
+    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True)
+    env.synchronize()
+    t_set = time.time() - t_set
+    stats = RolloutStats(B, M, dev)
+    gen = torch.Generator(device=dev).manual_seed(args.seed * 7919 + rank)
+
+    def policy():
+        return torch.rand((B, 3), generator=gen, device=dev, dtype=torch.float64)
+
+    r = env.reset()
+
+    def one_step():
+        nonlocal r
+        r = env.step(r["agent_id"], policy())
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize(dev)
+    c0 = env.counters()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"])
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    c1 = env.counters()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cnt = torch.tensor([c1["env_steps"] - c0["env_steps"], c1["ticks"], c1["exact_ticks"]], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    table = stats.gather()                                     # the path's one exchange step (RCCL all-gather)
+    elapsed = float(el[0]); env_steps = float(cnt[0])
+
+    # ---- per-kernel timing pass (HIP events on the stream the kernels are launched on) ----------------------
+    stream = torch.cuda.current_stream(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_env = t_obs = 0.0
+    ks = max(1, args.kernel_steps)
+    steps_before = env.counters()["env_steps"]
+    for _ in range(ks):
+        a = policy()
+        env._in_agent.copy_(r["agent_id"]); env._in_action.copy_(a)
+        ptrs = env._out_ptrs(); obs_ptr = ptrs.pop("obs")
+        ev[0].record(stream)
+        env._h.step(env._in_agent.data_ptr(), env._in_action.data_ptr(), True, obs=0, **ptrs)
+        ev[1].record(stream)
+        env._h.render(env.agent_id.data_ptr(), obs_ptr)
+        ev[2].record(stream)
+        torch.cuda.synchronize(dev)
+        t_env += ev[0].elapsed_time(ev[1]) * 1e-3
+        t_obs += ev[1].elapsed_time(ev[2]) * 1e-3
+    steps_k = env.counters()["env_steps"] - steps_before
+    phys_b, obs_b = algorithmic_bytes(N, T, M, G)
+    env_launch = t_env / ks; obs_launch = t_obs / ks
+    units = steps_k / ks                                        # env-steps one launch processes (auto-resets excluded)
+    if env_launch >= obs_launch:
+        dom, dur, per_unit = "wrsn_env_kernel", env_launch, phys_b
+    else:
+        dom, dur, per_unit = "wrsn_obs_kernel", obs_launch, obs_b
+    achieved = per_unit * units / dur / 1e9
+    peak = 8000.0
+
+    if rank == 0:
+        value = env_steps / elapsed
+        out = {
+            "metric": "env-steps/sec (whole node), 4096 envs x 200 nodes, 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (physics) / f32 (observation)", "data": "synthetic",
+            "config": {"workload": "%d envs/GPU x %d nodes x %d targets x %d MC, random policy U[0,1)^3, auto-reset, 4x%dx%d observation" % (B, N, T, M, G, G),
+                       "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "parallelism": "env-shard x%d" % world},
+            "env_steps_timed": env_steps, "sim_ticks_per_s": None, "mean_return_table_rows": int(table.shape[0]),
+            "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(t_set, 2)},
+            "kernels": {"wrsn_env_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                         "traffic": None, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
+                         "whole_step_achieved_GBps": (phys_b + obs_b) * value / 1e9, "whole_step_frac": (phys_b + obs_b) * value / 1e9 / peak},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            cores = os.cpu_count() or 1
+            threads = max(1, min(cores, 64))
+            v, n, dt = cpu_baseline(scenarios[:256], M, args.cpu_seconds, threads)
+            out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
+                                   "sample": "%d oracle env-steps (incl. get_state) in %.1f s on %d threads, same synthetic networks and action distribution" % (n, dt, threads)}
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -738,7 +738,7 @@ struct Sim {
         default: break;
         }
         pend = 0;
-        for (long guard = 0; guard < 400000000L; ++guard) {
+        for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
             int kind = -1, idx = 0; double bt = 0.0; int bp = 0; int64_t bs = 0;
 #define WRSN_CONSIDER(K, I, T_, P_, S_) if (kind < 0 || key_less((T_), (P_), (S_), bt, bp, bs)) { kind = (K); idx = (I); bt = (T_); bp = (P_); bs = (S_); }
             if (!frozen) {
@@ -789,7 +789,7 @@ struct Sim {
     // drive the environment until the run stops: lane 0 pops events, the wave serves its requests
     WDEV void run(bool use_limit, double limit) {
         double svc = 0.0;
-        for (;;) {
+        for (long guard = 0; guard < 8000000L; ++guard) {
             if (lane == 0) { int arg = 0; int req = scalar_run(svc, use_limit, limit, &arg); sReq[0] = req; sReq[1] = arg; }
             __syncthreads();
             const int req = sReq[0], arg = sReq[1];

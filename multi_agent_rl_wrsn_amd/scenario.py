@@ -107,66 +107,18 @@ def synth_scenario(seed, n_node=200, n_target=200, side=None, node_spec=None, ma
     every target inside the sensing range of a node that is connected to the base station at t = 0 --
     otherwise `Network.operate` declares the network dead at t = 0.1 (Network.py:76-77).
 
-    Counter-based RNG (Philox keyed by `seed`), so env e of a batch is reproducible from base_seed + e.
+    The generator itself is host code behind the C-ABI (`wrsn_synth_network`, csrc/wrsn_api.hip; its own
+    xoshiro256** stream keyed by `seed`), so env e of a batch is reproducible from base_seed + e and 4096
+    networks take well under a second.  side=None keeps the shipped node density (1000 m for <= 200 nodes).
     """
+    from . import _lib
     spec = dict(DEFAULT_NODE_SPEC if node_spec is None else node_spec)
-    if side is None:                              # keep the shipped node density: 1000 m for <= 200 nodes
-        side = 1000.0 * max(1.0, np.sqrt(n_node / 200.0))
-    rng = np.random.Generator(np.random.Philox(key=int(seed)))
-    com, sen = float(spec["com_range"]), float(spec["sen_range"])
-    bs = np.array([side / 2.0, side / 2.0])
-    hop_lo, hop_hi = 0.62 * com, 0.995 * com      # U[50, 80) m at the shipped com_range
-    min_sep = 0.56 * com                          # keeps chains apart: low degree, long routes
-    xy = np.empty((n_node, 2))
-    parent = np.full(n_node, -1, dtype=np.int64)
-    n = 0
-    n_direct = int(rng.integers(2, 5))
-    tips = []
-    tries = 0
-    while n < n_node:
-        tries += 1
-        if tries > 200000:
-            raise RuntimeError("synthetic generator failed to place %d nodes (seed %d)" % (n_node, seed))
-        if n < n_direct:
-            # direct nodes: inside the base station's reach
-            ang = rng.uniform(0, 2 * np.pi)
-            r = rng.uniform(0.35 * com, 0.95 * com)
-            p = bs + r * np.array([np.cos(ang), np.sin(ang)])
-            par = -1
-        else:
-            # extend a chain tip (chain-like growth) or branch off a random placed node
-            if tips and rng.random() < 0.93:
-                par = tips[int(rng.integers(0, len(tips)))]
-            else:
-                par = int(rng.integers(0, n))
-            out = xy[par] - bs
-            base = np.arctan2(out[1], out[0])
-            ang = base + rng.normal(0.0, 0.75)
-            r = rng.uniform(hop_lo, hop_hi)
-            p = xy[par] + r * np.array([np.cos(ang), np.sin(ang)])
-        if p[0] < 0 or p[0] > side or p[1] < 0 or p[1] > side:
-            continue
-        if n > 0:
-            d = np.hypot(xy[:n, 0] - p[0], xy[:n, 1] - p[1])
-            if d.min() < min_sep:
-                continue
-        xy[n] = p
-        parent[n] = par
-        if par in tips:
-            tips.remove(par)
-        tips.append(n)
-        if len(tips) > 24:
-            tips.pop(0)
-        n += 1
-    # targets: each within 0.93 * sen_range of some node (so it is covered), biased to the outer nodes
-    dist_bs = np.hypot(xy[:, 0] - bs[0], xy[:, 1] - bs[1])
-    w = 0.25 + dist_bs / dist_bs.max()
-    w = w / w.sum()
-    owner = rng.choice(n_node, size=n_target, p=w)
-    ang = rng.uniform(0, 2 * np.pi, size=n_target)
-    r = 0.93 * sen * np.sqrt(rng.uniform(0, 1, size=n_target))
-    txy = xy[owner] + np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)
-    return Scenario(node_xy=xy, target_xy=txy, bs_xy=bs, node_spec=spec, max_time=max_time, seed=int(seed),
+    lib = _lib.load()
+    node_xy = np.zeros((int(n_node), 2)); target_xy = np.zeros((int(n_target), 2)); bs = np.zeros(2)
+    _lib.check(lib, lib.wrsn_synth_network(int(seed), int(n_node), int(n_target), float(side or 0.0),
+                                           float(spec["com_range"]), float(spec["sen_range"]),
+                                           node_xy.ctypes.data, target_xy.ctypes.data, bs.ctypes.data))
+    return Scenario(node_xy=node_xy, target_xy=target_xy, bs_xy=bs, node_spec=spec, max_time=max_time, seed=int(seed),
                     name="synth_n%d_t%d_s%d" % (n_node, n_target, seed))
 
 
