@@ -32,13 +32,67 @@ enum {
 };
 
 // requests lane 0 posts to the wave
-enum { REQ_STOP = 0, REQ_NODE, REQ_UR, REQ_SL, REQ_PRECHECK, REQ_CONN };
+enum { REQ_STOP = 0, REQ_GRID, REQ_PRECHECK, REQ_CONN };
 
 // ------------------------------------------------------------------ wave-level primitives (64 lanes)
-WDEV double wv_sum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-WDEV double wv_max(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return v; }
-WDEV double wv_min(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o)); return v; }
-WDEV int wv_sumi(int v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+// Reductions run on the DPP crossbar of the VALU (quad_perm / row_half_mirror / row_mirror / row_bcast15 / row_bcast31:
+// a handful of cycles per step) instead of ds_bpermute round trips through the LDS; the total lands in lane 63 and
+// is broadcast with v_readlane.
+#define WRSN_DPP_QP_1032 0xB1
+#define WRSN_DPP_QP_2301 0x4E
+#define WRSN_DPP_ROW_HALF_MIRROR 0x141
+#define WRSN_DPP_ROW_MIRROR 0x140
+#define WRSN_DPP_ROW_BCAST15 0x142
+#define WRSN_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+WDEV double dpp_f64(double ident, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+WDEV double lane63_f64(double v) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+WDEV double wv_sum(double v) {
+    v += dpp_f64<WRSN_DPP_QP_1032, 0xf>(0.0, v);
+    v += dpp_f64<WRSN_DPP_QP_2301, 0xf>(0.0, v);
+    v += dpp_f64<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(0.0, v);
+    v += dpp_f64<WRSN_DPP_ROW_MIRROR, 0xf>(0.0, v);
+    v += dpp_f64<WRSN_DPP_ROW_BCAST15, 0xa>(0.0, v);
+    v += dpp_f64<WRSN_DPP_ROW_BCAST31, 0xc>(0.0, v);
+    return lane63_f64(v);
+}
+WDEV void wv_sum2(double& a, double& b) {                   // two independent sums, chains interleaved
+    a += dpp_f64<WRSN_DPP_QP_1032, 0xf>(0.0, a); b += dpp_f64<WRSN_DPP_QP_1032, 0xf>(0.0, b);
+    a += dpp_f64<WRSN_DPP_QP_2301, 0xf>(0.0, a); b += dpp_f64<WRSN_DPP_QP_2301, 0xf>(0.0, b);
+    a += dpp_f64<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(0.0, a); b += dpp_f64<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(0.0, b);
+    a += dpp_f64<WRSN_DPP_ROW_MIRROR, 0xf>(0.0, a); b += dpp_f64<WRSN_DPP_ROW_MIRROR, 0xf>(0.0, b);
+    a += dpp_f64<WRSN_DPP_ROW_BCAST15, 0xa>(0.0, a); b += dpp_f64<WRSN_DPP_ROW_BCAST15, 0xa>(0.0, b);
+    a += dpp_f64<WRSN_DPP_ROW_BCAST31, 0xc>(0.0, a); b += dpp_f64<WRSN_DPP_ROW_BCAST31, 0xc>(0.0, b);
+    a = lane63_f64(a); b = lane63_f64(b);
+}
+WDEV double wv_max(double v) {
+    const double id = -WRSN_INF;
+    v = fmax(v, dpp_f64<WRSN_DPP_QP_1032, 0xf>(id, v));
+    v = fmax(v, dpp_f64<WRSN_DPP_QP_2301, 0xf>(id, v));
+    v = fmax(v, dpp_f64<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(id, v));
+    v = fmax(v, dpp_f64<WRSN_DPP_ROW_MIRROR, 0xf>(id, v));
+    v = fmax(v, dpp_f64<WRSN_DPP_ROW_BCAST15, 0xa>(id, v));
+    v = fmax(v, dpp_f64<WRSN_DPP_ROW_BCAST31, 0xc>(id, v));
+    return lane63_f64(v);
+}
+WDEV double wv_min(double v) { return -wv_max(-v); }
+WDEV int wv_sumi(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, WRSN_DPP_QP_1032, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, WRSN_DPP_QP_2301, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, WRSN_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, WRSN_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, WRSN_DPP_ROW_BCAST15, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, WRSN_DPP_ROW_BCAST31, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 WDEV bool wv_any(bool p) { return __ballot(p) != 0ull; }
 WDEV int wv_scan_incl(int v, int lane) {
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }
@@ -66,21 +120,23 @@ struct Sim {
     WrsnThread* sTh;
     double* sCT; int64_t* sCS; int32_t *sCA, *sCTr, *sCP;
     double* sConnRate; int16_t* sConn;
-    int32_t* sReq;                     // mailbox: [0] request, [1] argument, [2] live charger-node connections
+    int32_t* sReq;                     // mailbox: [0] request, [1] argument, [2] live charger-node connections, [3] flags
+    double* sReqD;                     //          [0] time limit, [1] now, [2] seq (as int64)
     // node registers (per lane)
     double E[NPL], CS[NPL], d1[NPL], d2[NPL];
     unsigned am;                       // bit j: node j*64+lane alive
     double cap, thr;
-    // wave-uniform registers: identical in every lane, only changed inside wave services
+    // wave-uniform registers: identical in every lane.  `now` / `seq` are also advanced by lane 0 while it fires
+    // charger events; they are re-broadcast through the mailbox at every hand-off.
     double opmax;
-    int64_t n_ticks, n_exact;
+    int64_t n_ticks, n_exact, n_events;
     int alive, levels_dirty, cache_dirty, irreg, ring_len, ring_head, safe_ticks, log_pending, err;
-    // scalar registers: meaningful in lane 0 only
     double now; int64_t seq;
-    double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;
+    double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;   // pending grid items
+    int net_phase, net_active, node_phase, frozen, deaths_flag;
     double last_minfit;
-    int64_t n_events;
-    int net_phase, net_active, node_phase, frozen, L, pend, pend_idx;
+    // scalar registers: meaningful in lane 0 only
+    int L, pend, pend_idx;
 
     // -------------------------------------------------------------- setup of pointers
     WDEV void bind(const WrsnDev& d, int env_, int lane_, double* smem) {
@@ -103,9 +159,9 @@ struct Sim {
         sConnRate = (double*)p;
         sConn = (int16_t*)(sConnRate + M * WRSN_CONN_CAP);
         p = (uintptr_t)(sConn + M * WRSN_CONN_CAP); p = (p + 7) & ~(uintptr_t)7;
-        sReq = (int32_t*)p;
+        sReq = (int32_t*)p; sReqD = (double*)(sReq + 4);
         cap = ec->capacity; thr = ec->threshold;
-        err = 0; pend = 0; pend_idx = 0; L = 0;
+        err = 0; pend = 0; pend_idx = 0; L = 0; deaths_flag = 0;
     }
 
     // -------------------------------------------------------------- state load / store
@@ -355,15 +411,14 @@ struct Sim {
             }
             E[j] = e_end;
         }
-        if (wv_any(died)) { cache_dirty = 1; levels_dirty = 1; }
+        if (wv_any(died)) { cache_dirty = 1; levels_dirty = 1; deaths_flag = 1; }
         irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++;
         __syncthreads();
     }
 
     // -------------------------------------------------------------- k+0.5: Node.operate first half for all nodes (Node.py:57-62)
-    WDEV void node_half() {
+    WDEV void node_half(const double (&rrh)[NPL], const bool any_rr) {
         if (cache_dirty) rebuild_cache();
-        const bool any_rr = sReq[2] > 0;
         bool fast = true;
         if (safe_ticks > 0) { safe_ticks--; }
         else {
@@ -371,11 +426,11 @@ struct Sim {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 if ((am >> j) & 1u) {
-                    int i = j * 64 + lane;
-                    double rr = any_rr ? sRR[i] * 0.5 : 0.0;
+                    double rr = rrh[j];
                     double a = E[j] - d1[j];
                     double b = fmin(a + rr, cap) - d2[j];
-                    if (a - thr < opmax || b - thr < opmax) trig = true;
+                    // a node can only run dry while it pays for an operation: idle nodes never trigger
+                    if ((d1[j] > 0.0 && a - thr < opmax) || (d2[j] > 0.0 && b - thr < opmax)) trig = true;
                     double ds = d1[j] + d2[j];
                     if (ds > 0.0) mn = fmin(mn, (E[j] - thr - opmax) / ds);
                 }
@@ -386,7 +441,7 @@ struct Sim {
         if (fast) {
             if (any_rr) {
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) { int i = j * 64 + lane; E[j] = fmin(E[j] - d1[j] + sRR[i] * 0.5, cap) - d2[j]; }
+                for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) E[j] = fmin(E[j] - d1[j] + rrh[j], cap) - d2[j];
             } else {
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) E[j] = (E[j] - d1[j]) - d2[j];
@@ -396,10 +451,10 @@ struct Sim {
     }
 
     // -------------------------------------------------------------- k+1.0: second half + consumption window (Node.py:65-77)
-    WDEV void node_full() {
-        if (sReq[2] > 0) {
+    WDEV void node_full(const double (&rrh)[NPL], const bool any_rr) {
+        if (any_rr) {
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) { int i = j * 64 + lane; E[j] = fmin(E[j] + sRR[i] * 0.5, cap); }
+            for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) E[j] = fmin(E[j] + rrh[j], cap);
         }
         if (irreg > 0) {
             const int len = ring_len, head = ring_head;
@@ -418,14 +473,6 @@ struct Sim {
         log_pending = 0; n_ticks++;
     }
 
-    // value of a per-node register of node i, in every lane
-    WDEV double fetch(const double (&v)[NPL], int i) const {
-        double r = 0.0; int src = i & 63, jj = i >> 6;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) { double t = __shfl(v[j], src); if (j == jj) r = t; }
-        return r;
-    }
-
     WDEV double conn_rate_of(int m, int k, int i) const {    // alpha / (dist(node, charger) + beta)^2 (Node.py:137, WRSN.py:122)
         if (sAg[m].loc[0] == sAg[m].conn_loc[0] && sAg[m].loc[1] == sAg[m].conn_loc[1]) return sConnRate[m * WRSN_CONN_CAP + k];
         double dd = dist2(nx[i], ny[i], sAg[m].loc[0], sAg[m].loc[1]) + ec->beta;
@@ -433,16 +480,19 @@ struct Sim {
     }
 
     // -------------------------------------------------------------- WRSN.update_reward (WRSN.py:100-127)
+    // priorities: p = CS / (E - thr + 1e-9) (0 for dead nodes), standardised (population std), exp, normalised.
+    // mean and variance come from one fused pair of sums; the node that owns a connected entry computes its own
+    // contribution and posts it to LDS, lane 0 adds them up in list order.
     WDEV void update_reward() {
         const double eps = 1e-9;
-        double x[NPL]; double s = 0.0;
+        double x[NPL]; double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) { x[j] = ((am >> j) & 1u) ? (CS[j] / (E[j] - thr + eps)) : 0.0; s += x[j]; }
-        double mean = wv_sum(s) / N;
-        double v = 0.0;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) if (j * 64 + lane < N) v += (x[j] - mean) * (x[j] - mean);
-        double sd = sqrt(wv_sum(v) / N);
+        for (int j = 0; j < NPL; ++j) { x[j] = ((am >> j) & 1u) ? (CS[j] / (E[j] - thr + eps)) : 0.0; s1 += x[j]; s2 += x[j] * x[j]; }
+        wv_sum2(s1, s2);
+        const double mean = s1 / N;
+        double var = s2 / N - mean * mean;
+        if (!(var > 0.0)) var = 0.0;
+        double sd = sqrt(var);
         if (sd == 0.0) sd = eps;
         double ex[NPL]; double es = 0.0;
 #pragma unroll
@@ -450,20 +500,38 @@ struct Sim {
         double tot = wv_sum(es);
         if (tot == 0.0) tot = eps;
         const double a_b2 = ec->alpha / (ec->beta * ec->beta);
+        double* post = sU;                                   // [M][CONN_CAP] contributions
         for (int m = 0; m < M; ++m) {
             if (sAg[m].status == 0 || !sAg[m].type_charging) continue;
-            double incentive = 0.0; const int nc = sAg[m].n_conn;
+            const int nc = sAg[m].n_conn;
             for (int k = 0; k < nc; ++k) {
-                int i = sConn[m * WRSN_CONN_CAP + k];
-                if (!(sLS[i] & 1)) continue;
-                double Ei = fetch(E, i), Ci = fetch(CS, i), pi = fetch(ex, i) / tot;
-                double rate = conn_rate_of(m, k, i);
-                double e_no = fmin(Ei - Ci, thr);            // min / max as written (WRSN.py:123-124)
-                double e_with = fmax(Ei - Ci + rate, cap);
-                incentive += pi * (e_with - e_no) / a_b2;
+                const int i = sConn[m * WRSN_CONN_CAP + k];
+                if (lane == (i & 63)) {
+                    const int jj = i >> 6;
+                    double Ei = E[0], Ci = CS[0], xi = ex[0];
+#pragma unroll
+                    for (int j = 1; j < NPL; ++j) if (j == jj) { Ei = E[j]; Ci = CS[j]; xi = ex[j]; }
+                    double c = 0.0;
+                    if (sLS[i] & 1) {
+                        const double rate = conn_rate_of(m, k, i);
+                        const double e_no = fmin(Ei - Ci, thr);          // min / max as written (WRSN.py:123-124)
+                        const double e_with = fmax(Ei - Ci + rate, cap);
+                        c = (xi / tot) * (e_with - e_no) / a_b2;
+                    }
+                    post[m * WRSN_CONN_CAP + k] = c;
+                }
             }
-            if (lane == 0) sAg[m].excl += incentive;         // nobody else reads excl inside this service
         }
+        __syncthreads();
+        if (lane == 0) {
+            for (int m = 0; m < M; ++m) {
+                if (sAg[m].status == 0 || !sAg[m].type_charging) continue;
+                double incentive = 0.0; const int nc = sAg[m].n_conn;
+                for (int k = 0; k < nc; ++k) incentive += post[m * WRSN_CONN_CAP + k];
+                sAg[m].excl += incentive;
+            }
+        }
+        __syncthreads();
     }
 
     // -------------------------------------------------------------- WRSN.get_network_fitness -> np.min (WRSN.py:188-220)
@@ -549,12 +617,140 @@ struct Sim {
         if (lane == 0) { sAg[a].n_conn = cnt; sAg[a].conn_loc[0] = lx; sAg[a].conn_loc[1] = ly; }
     }
 
+    // ============================================================== GRID LOOP (all lanes, wave-uniform registers)
+    // The periodic items of the reference -- Network.operate (k+0.1 setLevels/check_targets, k+1.0 alive check),
+    // update_reward (k+1.0) and the Node.operate block (k+0.5, k+1.0) -- are popped here in (time, seq) order until the
+    // next item would not be strictly earlier than `t_limit` (the next charger / condition event).  When no node is
+    // being charged, no reward priority is consumed, the consumption window is uniform and no node can run dry, whole
+    // seconds are skipped in closed form (E -= j * (d1 + d2)).
+    WDEV void grid_run(double t_limit, bool one, bool ur_flag) {
+        deaths_flag = 0;
+        // Node.energyRR only changes when lane 0 connects / disconnects a charger, i.e. between two grid services
+        const bool any_rr = sReq[2] > 0;
+        double rrh[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) rrh[j] = any_rr ? sRR[j * 64 + lane] * 0.5 : 0.0;
+        for (long guard = 0; guard < 4000000L; ++guard) {
+            if (frozen) break;
+            int k = 1; double bt = ur_time; int64_t bs = ur_seq;
+            if (node_time < bt || (node_time == bt && node_seq < bs)) { k = 2; bt = node_time; bs = node_seq; }
+            if (net_active && (net_time < bt || (net_time == bt && net_seq < bs))) { k = 0; bt = net_time; bs = net_seq; }
+            if (!one && !(bt < t_limit)) break;
+            // ---- canonical start of a second: setLevels @k+0.1 (no-op), nodes @k+0.5, reward/alive-check/nodes @k+1.0
+            const double kk = floor(bt);
+            if (!one && node_phase == 0 && (net_active ? (k == 0 && net_phase == 0) : (k == 2)) && !levels_dirty && ur_time == kk + 1.0) {
+                if (!any_rr && !ur_flag && irreg == 0 && !cache_dirty && !log_pending && safe_ticks > 0) {
+                    // nothing but the constant per-second drain happens: skip j whole seconds in closed form
+                    double jf = floor(fmin(t_limit, kk + 1.0e6) - kk);
+                    if (kk + jf >= t_limit) jf -= 1.0;
+                    if (net_active) { double jm = floor(fmin(ec->max_time, kk + 1.0e6) - kk); if (kk + jm >= ec->max_time) jm -= 1.0; jf = fmin(jf, jm); }
+                    const int j = (int)fmin(jf, (double)safe_ticks);
+                    if (j >= 1) {
+                        const double dj = (double)j;
+#pragma unroll
+                        for (int q = 0; q < NPL; ++q) E[q] -= dj * (d1[q] + d2[q]);
+                        const double ke = kk + dj;
+                        ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
+                        if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; n_events += 5 * (int64_t)j; }
+                        else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; n_events += 3 * (int64_t)j; }
+                        now = ke; n_ticks += j; safe_ticks -= j;
+                        continue;
+                    }
+                }
+                if (kk + 1.0 < t_limit && (!net_active || kk + 1.0 < ec->max_time)) {
+                    // one whole second, straight-line: the five items keep their order, nothing can interleave
+                    now = kk + 1.0 * 0.5;
+                    node_half(rrh, any_rr);
+                    if (deaths_flag) {                       // lane 0 must re-plan chargers before time moves on
+                        if (net_active) { const double t1 = kk + 1.0 / 10.0; net_phase = 1; net_time = t1 + 9.0 * 1.0 / 10.0; net_seq = seq++; n_events++; }
+                        node_phase = 1; node_time = now + 1.0 * 0.5; node_seq = seq++; n_events++;
+                        break;
+                    }
+                    now = kk + 1.0;
+                    if (ur_flag) update_reward();
+                    node_full(rrh, any_rr);
+                    ur_time = now + 1.0; node_time = now + 1.0 * 0.5;
+                    if (net_active) { net_time = now + 1.0 / 10.0; seq += 5; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; n_events += 5; }
+                    else { seq += 3; ur_seq = seq - 2; node_seq = seq - 1; n_events += 3; }
+                    continue;
+                }
+            }
+            // ---- generic path: one item
+            now = bt; n_events++;
+            if (k == 0) {
+                if (net_phase == 0) {                        // Network.py:75-78
+                    if (levels_dirty) set_levels();
+                    if (alive == 0) frozen = 1;              // terminal at the next return; node state is no longer observable
+                    net_phase = 1; net_time = now + 9.0 * 1.0 / 10.0; net_seq = seq++;
+                } else {                                     // Network.py:78-80
+                    if (alive == 0 || now >= ec->max_time) net_active = 0;
+                    else { net_phase = 0; net_time = now + 1.0 / 10.0; net_seq = seq++; }
+                }
+            } else if (k == 1) {
+                if (ur_flag) update_reward();
+                ur_time = now + 1.0; ur_seq = seq++;
+            } else {
+                if (node_phase == 0) { node_half(rrh, any_rr); node_phase = 1; } else { node_full(rrh, any_rr); node_phase = 0; }
+                node_time = now + 1.0 * 0.5; node_seq = seq++;
+            }
+            if (one || deaths_flag) break;
+        }
+    }
+
     // ============================================================== SCALAR EVENT PROCESSOR (lane 0 only)
 
     WDEV void th_sched(int ti, int pc, int prio, double time) { sTh[ti].pc = pc; sTh[ti].prio = prio; sTh[ti].time = time; sTh[ti].seq = seq++; }
 
     WDEV void mc_check_status(int a) {                       // MobileCharger.py:134-140
         if (sAg[a].energy <= ec->mc_threshold) { sAg[a].status = 0; sAg[a].energy = ec->mc_threshold; }
+    }
+
+    WDEV bool agent_single(int a, int ti) const {            // no other live operate_step process acts on this charger
+        for (int i = 0; i < 2 * M; ++i) {
+            if (i == ti) continue;
+            int pc = sTh[i].pc;
+            if (pc != PC_NONE && pc != PC_FINISHED && sTh[i].agent == a) return false;
+        }
+        return true;
+    }
+
+    // ---- fast-forward: unit sub-steps of move() / charge() whose only effect is on the charger itself are kept
+    // virtual and applied lazily (identical arithmetic, applied in order); the process resumes at the timeout of the
+    // last unit sub-step.  Only taken in generic position; ties with the node grid use the per-sub-step path.
+    WDEV void ff_apply(int ti, double t, bool all) {
+        const int a = sTh[ti].agent;
+        int n = sTh[ti].ff_n; double ft = sTh[ti].ff_t;
+        if (sTh[ti].ff == 1) {
+            const double ux = sTh[ti].mvec[0] / sTh[ti].total_time * 1.0, uy = sTh[ti].mvec[1] / sTh[ti].total_time * 1.0;
+            const double de = ec->pm * 1.0 * ec->velocity;
+            double lx = sAg[a].loc[0], ly = sAg[a].loc[1], e = sAg[a].energy;
+            while (n > 0 && (all || ft + 1.0 <= t)) { lx = lx + ux; ly = ly + uy; e -= de; ft = ft + 1.0; --n; }
+            sAg[a].loc[0] = lx; sAg[a].loc[1] = ly; sAg[a].energy = e;
+        } else if (sTh[ti].ff == 2) {
+            const double cr = sAg[a].charging_rate;
+            double e = sAg[a].energy, c2 = sAg[a].cur[2], tmp = sTh[ti].tmp;
+            while (n > 0 && (all || ft + 1.0 <= t)) {
+                e = e - cr * 1.0; c2 = (c2 - 1.0) > 0.0 ? (c2 - 1.0) : 0.0; tmp -= 1.0; ft = ft + 1.0; --n;
+            }
+            sAg[a].energy = e; sAg[a].cur[2] = c2; sTh[ti].tmp = tmp;
+        }
+        sTh[ti].ff_n = n; sTh[ti].ff_t = ft;
+        if (n == 0) sTh[ti].ff = 0;
+    }
+
+    WDEV void ff_sync_all(double t) {
+        for (int i = 0; i < 2 * M; ++i) if (sTh[i].ff != 0 && sTh[i].pc != PC_NONE && sTh[i].pc != PC_FINISHED) ff_apply(i, t, false);
+    }
+
+    // a connected node died (or a second process now shares the charger): return to the per-sub-step path at the
+    // sub-step in flight
+    WDEV void ff_fallback(int ti) {
+        if (sTh[ti].ff == 0) return;
+        ff_apply(ti, now, false);
+        if (sTh[ti].ff == 0) return;                         // everything virtual was already due: the resume event stands
+        const int kind = sTh[ti].ff;
+        sTh[ti].ff = 0; sTh[ti].ff_n = 0;
+        th_sched(ti, kind == 1 ? PC_MSTEP_TIMEOUT : PC_CSTEP_TIMEOUT, WRSN_NORMAL, sTh[ti].ff_t + 1.0);
     }
 
     WDEV void mc_move_loop(int ti) {                         // MobileCharger.py:85-94 from the top of `while True`
@@ -564,23 +760,28 @@ struct Sim {
         double mt = dist2(sTh[ti].m_dest[0], sTh[ti].m_dest[1], sAg[a].loc[0], sAg[a].loc[1]) / ec->velocity;
         sTh[ti].moving_time = mt;
         double s = mt < 1.0 ? mt : 1.0;
-        double lim = (sAg[a].energy - ec->mc_threshold) / (ec->pm * ec->velocity);
+        const double pmv = ec->pm * ec->velocity;
+        double lim = (sAg[a].energy - ec->mc_threshold) / pmv;
         sTh[ti].span = s < lim ? s : lim;
+        // fast-forward: a moving charger is observed by nobody until the run returns -- except through update_reward
+        // when it is (stale) "charging" with connected nodes -- so whole-second sub-steps can stay virtual
+        if (mt > 3.0 && lim > 3.0 && !(sAg[a].type_charging && sAg[a].n_conn > 0) && agent_single(a, ti)) {
+            double nf = floor(fmin(mt, lim)) - 1.0;          // the remainder (> 1 s) and the energy margin go through the exact path
+            if (nf > 100000.0) nf = 100000.0;
+            int n = (int)nf;
+            if (n >= 2) {
+                double t = now;
+                for (int q = 0; q < n; ++q) t = t + 1.0;     // same float accumulation as n successive timeouts
+                sTh[ti].span = 1.0; sTh[ti].ff = 1; sTh[ti].ff_n = n - 1; sTh[ti].ff_t = now;
+                th_sched(ti, PC_MSTEP_TIMEOUT, WRSN_NORMAL, t);
+                return;
+            }
+        }
         th_sched(ti, PC_MSTEP_INIT, WRSN_URGENT, now);
     }
 
-    WDEV void mc_charge_loop(int ti) {                       // MobileCharger.py:59-69 from the top of `while True`
-        int a = sTh[ti].agent;
-        if (sTh[ti].tmp == 0.0) { th_sched(ti, PC_CHG_DONE, WRSN_NORMAL, now); return; }
-        if (sAg[a].status == 0) { sAg[a].cur[2] = 0.0; th_sched(ti, PC_CHG_DEADWAIT, WRSN_NORMAL, now + sTh[ti].tmp); return; }
-        double span = sTh[ti].tmp < 1.0 ? sTh[ti].tmp : 1.0;
-        if (sAg[a].charging_rate != 0.0) { double lim = (sAg[a].energy - ec->mc_threshold) / sAg[a].charging_rate; if (lim < span) span = lim; }
-        sTh[ti].cspan = span;
-        th_sched(ti, PC_CSTEP_INIT, WRSN_URGENT, now);
-    }
-
     // Node.charger_connection / charger_disconnection over connected_nodes (Node.py:134-146); sign = +1 / -1
-    WDEV void mc_connect(int a, double sign) {
+    WDEV int mc_connect(int a, double sign) {
         const int nc = sAg[a].n_conn;
         double cr = sAg[a].charging_rate; int cnt = 0;
         for (int k = 0; k < nc; ++k) {
@@ -592,6 +793,40 @@ struct Sim {
         sAg[a].charging_rate = cr;
         if (sign > 0) { sAg[a].n_live = cnt; sReq[2] += cnt; }
         else { sReq[2] -= sAg[a].n_live; sAg[a].n_live = 0; if (sReq[2] < 0) sReq[2] = 0; }
+        return cnt;
+    }
+
+    WDEV void mc_charge_loop(int ti) {                       // MobileCharger.py:59-69 from the top of `while True`
+        int a = sTh[ti].agent;
+        if (sTh[ti].tmp == 0.0) { th_sched(ti, PC_CHG_DONE, WRSN_NORMAL, now); return; }
+        if (sAg[a].status == 0) { sAg[a].cur[2] = 0.0; th_sched(ti, PC_CHG_DEADWAIT, WRSN_NORMAL, now + sTh[ti].tmp); return; }
+        double span = sTh[ti].tmp < 1.0 ? sTh[ti].tmp : 1.0;
+        if (sAg[a].charging_rate != 0.0) { double lim = (sAg[a].energy - ec->mc_threshold) / sAg[a].charging_rate; if (lim < span) span = lim; }
+        sTh[ti].cspan = span;
+        // fast-forward: in generic position (no sub-step boundary on a node sampling instant k+0.5 / k+1.0) the
+        // disconnect/reconnect pair of every boundary cancels, so the connection is made once and the whole-second
+        // sub-steps stay virtual.  A node death or the charger running dry return to the exact path.
+        const double tmp = sTh[ti].tmp;
+        const double fr = now - floor(now);
+        if (tmp > 3.0 && fr != 0.0 && fr != 0.5 && sAg[a].charging_rate == 0.0 && agent_single(a, ti)) {
+            double nf = floor(tmp); if (nf == tmp) nf -= 1.0;          // unit sub-steps that are not the last one
+            // rate this sub-step would connect with
+            double cr = 0.0; const int nc = sAg[a].n_conn;
+            for (int k = 0; k < nc; ++k) { int i = sConn[a * WRSN_CONN_CAP + k]; if (sLS[i] & 1) cr += conn_rate_of(a, k, i); }
+            if (cr > 0.0) { double ne = floor((sAg[a].energy - ec->mc_threshold) / cr) - 1.0; if (ne < nf) nf = ne; }
+            if (nf > 100000.0) nf = 100000.0;
+            int n = (int)nf;
+            bool ok = n >= 2;
+            double t = now;
+            for (int q = 0; q < n && ok; ++q) { t = t + 1.0; double f2 = t - floor(t); if (f2 == 0.0 || f2 == 0.5) ok = false; }
+            if (ok) {
+                mc_connect(a, 1.0);                          // charge_step #1 connects (MobileCharger.py:40-41)
+                sTh[ti].cspan = 1.0; sTh[ti].ff = 2; sTh[ti].ff_n = n - 1; sTh[ti].ff_t = now;
+                th_sched(ti, PC_CSTEP_TIMEOUT, WRSN_NORMAL, t);
+                return;
+            }
+        }
+        th_sched(ti, PC_CSTEP_INIT, WRSN_URGENT, now);
     }
 
     WDEV void cond_trigger(int j) {                          // Condition.succeed(): NORMAL at now
@@ -615,8 +850,10 @@ struct Sim {
     // returns a wave request (REQ_PRECHECK / REQ_CONN) or 0
     WDEV int thread_fire(int ti) {
         const int a = sTh[ti].agent;
+        if (sTh[ti].ff != 0) ff_apply(ti, now, true);        // the resume event: every virtual sub-step precedes it
         switch (sTh[ti].pc) {
         case PC_P_INIT:                                      // MobileCharger.py:105-115: needs the O(N) sum
+            for (int i = 0; i < 2 * M; ++i) if (i != ti && sTh[i].agent == a) ff_fallback(i);   // a second process on this charger
             pend = REQ_PRECHECK; pend_idx = ti; return REQ_PRECHECK;
         case PC_MOVE_INIT: {                                 // MobileCharger.py:82-84
             double mt = dist2(sTh[ti].m_dest[0], sTh[ti].m_dest[1], sAg[a].loc[0], sAg[a].loc[1]) / ec->velocity;
@@ -699,6 +936,7 @@ struct Sim {
             if (pc == PC_NONE || (pc == PC_FINISHED && sAg[sTh[i].agent].cur_thread != i)) {
                 sTh[i].agent = agent; sTh[i].phy[0] = p0; sTh[i].phy[1] = p1; sTh[i].phy[2] = p2;
                 sTh[i].stage = 0; sTh[i].moving_time = 0; sTh[i].total_time = 0; sTh[i].span = 0; sTh[i].tmp = 0; sTh[i].cspan = 0;
+                sTh[i].ff = 0; sTh[i].ff_n = 0; sTh[i].ff_t = 0;
                 th_sched(i, PC_P_INIT, WRSN_URGENT, now);
                 return i;
             }
@@ -710,14 +948,18 @@ struct Sim {
         return dist2(sAg[m].loc[0], sAg[m].loc[1], sAg[m].cur[0], sAg[m].cur[1]) < 1e-9 && sAg[m].cur[2] == 0.0;
     }
 
-    WDEV bool ur_needed() const {                            // does any charger consume the priorities? (WRSN.py:116-126)
-        for (int m = 0; m < M; ++m) if (sAg[m].status != 0 && sAg[m].type_charging && sAg[m].n_conn > 0) return true;
-        return false;
-    }
-
-    WDEV void sl_tail() {                                    // Network.py:76-78 after setLevels
-        if (alive == 0) frozen = 1;                          // terminal at the next return; node state is no longer observable
-        net_phase = 1; net_time = now + 9.0 * 1.0 / 10.0; net_seq = seq++;
+    // update_reward consumes the priorities only for alive chargers whose action type is "charging" and that have
+    // connected nodes (WRSN.py:116-126); bit 1: such a charger is being moved by a (stale) process, so its location
+    // has to be brought up to date before every reward instant
+    WDEV int ur_flags() const {
+        int f = 0;
+        for (int m = 0; m < M; ++m) {
+            if (sAg[m].status != 0 && sAg[m].type_charging && sAg[m].n_conn > 0) {
+                f |= 1;
+                for (int i = 0; i < 2 * M; ++i) if (sTh[i].agent == m && sTh[i].ff == 1 && sTh[i].pc != PC_NONE && sTh[i].pc != PC_FINISHED) f |= 2;
+            }
+        }
+        return f;
     }
 
     WDEV static bool key_less(double t1, int p1, int64_t s1, double t2, int p2, int64_t s2) {
@@ -726,84 +968,91 @@ struct Sim {
         return s1 < s2;
     }
 
-    // Run the event machine until a wave service is needed (returns its code, argument in *arg) or the run stops
-    // (REQ_STOP).  `svc` is the result of the previous service (the pre-check sum).
-    WDEV int scalar_run(double svc, bool use_limit, double limit, int* arg) {
+    // Fire charger / condition events in order until the wave has to do something: run the grid up to the next
+    // event (REQ_GRID), an O(N) service (REQ_PRECHECK / REQ_CONN), or the run stops (REQ_STOP).
+    WDEV int scalar_run(double svc, bool use_limit, double limit, int* arg, double* t_lim_out, int* flags_out) {
         switch (pend) {                                      // finish the item that asked for the service
-        case REQ_NODE: node_phase ^= 1; node_time = now + 1.0 * 0.5; node_seq = seq++; break;
-        case REQ_UR: ur_time = now + 1.0; ur_seq = seq++; break;
-        case REQ_SL: sl_tail(); break;
         case REQ_PRECHECK: p_init_tail(pend_idx, svc); break;
         case REQ_CONN: mc_charge_loop(pend_idx); break;
+        case REQ_GRID:
+            if (deaths_flag) {                               // a node died: chargers connected to it re-plan on the exact path
+                for (int i = 0; i < 2 * M; ++i) if (sTh[i].ff == 2 && sTh[i].pc != PC_NONE && sTh[i].pc != PC_FINISHED && sAg[sTh[i].agent].n_live > 0) ff_fallback(i);
+            }
+            break;
         default: break;
         }
         pend = 0;
         for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
             int kind = -1, idx = 0; double bt = 0.0; int bp = 0; int64_t bs = 0;
 #define WRSN_CONSIDER(K, I, T_, P_, S_) if (kind < 0 || key_less((T_), (P_), (S_), bt, bp, bs)) { kind = (K); idx = (I); bt = (T_); bp = (P_); bs = (S_); }
-            if (!frozen) {
-                if (net_active) { WRSN_CONSIDER(0, 0, net_time, WRSN_NORMAL, net_seq) }
-                WRSN_CONSIDER(1, 0, ur_time, WRSN_NORMAL, ur_seq)
-                WRSN_CONSIDER(2, 0, node_time, WRSN_NORMAL, node_seq)
-            }
             for (int i = 0; i < 2 * M; ++i) {
                 int pc = sTh[i].pc;
                 if (pc != PC_NONE && pc != PC_FINISHED) { WRSN_CONSIDER(3, i, sTh[i].time, sTh[i].prio, sTh[i].seq) }
             }
             for (int j = 1; j <= L; ++j) if (sCP[j]) { WRSN_CONSIDER(4, j, sCT[j], WRSN_NORMAL, sCS[j]) }
 #undef WRSN_CONSIDER
-            if (kind < 0) { err = -7; return REQ_STOP; }     // nothing pending: cannot happen while a charger process runs
-            if (use_limit && !(bt < limit)) { now = limit; return REQ_STOP; }
+            const bool have_ev = kind >= 0;
+            // next grid item (wave-uniform registers; lane 0 holds the same copy)
+            bool have_grid = !frozen;
+            double gt = ur_time; int64_t gs = ur_seq;
+            if (have_grid) {
+                if (node_time < gt || (node_time == gt && node_seq < gs)) { gt = node_time; gs = node_seq; }
+                if (net_active && (net_time < gt || (net_time == gt && net_seq < gs))) { gt = net_time; gs = net_seq; }
+            }
+            if (!have_ev && !have_grid) { err = -7; return REQ_STOP; }      // cannot happen while a charger process runs
+            double t_lim = have_ev ? bt : WRSN_INF;
+            if (use_limit && limit < t_lim) t_lim = limit;
+            if (have_grid && gt < t_lim) {
+                const int uf = ur_flags();
+                if (uf & 2) { ff_sync_all(gt); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
+                else *arg = 0;
+                *t_lim_out = t_lim; *flags_out = uf & 1;
+                pend = REQ_GRID; return REQ_GRID;
+            }
+            if (use_limit && !(have_ev && bt < limit)) { now = limit; return REQ_STOP; }
+            if (have_grid && have_ev && gt == bt && key_less(gt, WRSN_NORMAL, gs, bt, bp, bs)) {
+                const int uf = ur_flags();
+                if (uf & 2) ff_sync_all(gt);
+                *arg = 1; *t_lim_out = t_lim; *flags_out = uf & 1;
+                pend = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
+            }
             now = bt; n_events++;
-            switch (kind) {
-            case 0:
-                if (net_phase == 0) {                        // Network.py:75-78
-                    if (levels_dirty) { pend = REQ_SL; return REQ_SL; }
-                    sl_tail();
-                } else {                                     // Network.py:78-80
-                    if (alive == 0 || now >= ec->max_time) net_active = 0;
-                    else { net_phase = 0; net_time = now + 1.0 / 10.0; net_seq = seq++; }
-                }
-                break;
-            case 1:
-                if (ur_needed()) { pend = REQ_UR; return REQ_UR; }
-                ur_time = now + 1.0; ur_seq = seq++;
-                break;
-            case 2:
-                pend = REQ_NODE; *arg = node_phase; return REQ_NODE;
-            case 3: {
+            if (kind == 3) {
                 int r = thread_fire(idx);
                 if (r) { *arg = (r == REQ_CONN) ? sTh[idx].agent : idx; return r; }
-                break; }
-            case 4:
+            } else {
                 sCP[idx] = 0;
                 if (idx == L) return REQ_STOP;               // StopSimulation
                 cond_trigger(idx + 1);
-                break;
             }
         }
         err = -6;
         return REQ_STOP;
     }
 
-    // drive the environment until the run stops: lane 0 pops events, the wave serves its requests
+    // drive the environment until the run stops: lane 0 fires charger events, the wave runs the grid and the O(N) services
     WDEV void run(bool use_limit, double limit) {
         double svc = 0.0;
         for (long guard = 0; guard < 8000000L; ++guard) {
-            if (lane == 0) { int arg = 0; int req = scalar_run(svc, use_limit, limit, &arg); sReq[0] = req; sReq[1] = arg; }
+            if (lane == 0) {
+                int arg = 0, fl = 0; double tl = 0.0;
+                int req = scalar_run(svc, use_limit, limit, &arg, &tl, &fl);
+                sReq[0] = req; sReq[1] = arg; sReq[3] = fl; sReqD[0] = tl; sReqD[1] = now; ((int64_t*)sReqD)[2] = seq;
+            }
             __syncthreads();
             const int req = sReq[0], arg = sReq[1];
+            now = sReqD[1]; seq = ((const int64_t*)sReqD)[2];      // lane 0 advanced them while firing events
             if (req == REQ_STOP) break;
             switch (req) {
-            case REQ_NODE: if (arg == 0) node_half(); else node_full(); break;
-            case REQ_UR: update_reward(); break;
-            case REQ_SL: set_levels(); break;
+            case REQ_GRID: grid_run(sReqD[0], arg != 0, sReq[3] != 0); break;
             case REQ_PRECHECK: svc = precheck(arg); break;
             case REQ_CONN: conn_build(arg); break;
             default: break;
             }
             __syncthreads();
         }
+        __syncthreads();
+        if (lane == 0) ff_sync_all(now);                     // bring virtual charger sub-steps up to the return instant
         __syncthreads();
     }
 };

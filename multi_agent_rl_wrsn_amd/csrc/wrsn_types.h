@@ -39,7 +39,9 @@ struct WrsnThread {
     double phy[3];
     double m_dest[2], moving_time, mvec[2], total_time, span;   // move() locals
     double tmp, cspan;                                          // charge() locals
+    double ff_t;                                                // fast-forward: end time of the last applied unit sub-step
     int32_t pc, agent, prio, stage;
+    int32_t ff, ff_n;                                           // fast-forward kind (0 none, 1 move, 2 charge) and unit sub-steps still virtual
 };
 
 // everything else that persists between two step() calls of one environment

@@ -74,6 +74,31 @@ inline unsigned long long __ballot(int pred) {
     for (unsigned l = 0; l < blockDim.x && l < 64; ++l) if (emu_slots[p][l][0]) m |= 1ull << l;
     return m;
 }
+
+// ---- DPP / readlane builtins used by the wave reductions (only the controls the product uses)
+inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_mask*/, bool /*bound_ctrl*/) {
+    const int l = (int)threadIdx.x, row = l >> 4;
+    int from = -1;
+    switch (ctrl) {
+    case 0xB1: from = (l & ~3) | ((l & 3) ^ 1); break;
+    case 0x4E: from = (l & ~3) | ((l & 3) ^ 2); break;
+    case 0x141: from = (l & ~7) | (7 - (l & 7)); break;
+    case 0x140: from = (l & ~15) | (15 - (l & 15)); break;
+    case 0x142: from = row >= 1 ? (row - 1) * 16 + 15 : -1; break;
+    case 0x143: from = l >= 32 ? 31 : -1; break;
+    default: std::abort();
+    }
+    const int got = emu_exchange(src, from < 0 ? l : from);   // every lane takes part in the rendezvous
+    const bool enabled = (row_mask >> row) & 1;
+    return (enabled && from >= 0) ? got : old;
+}
+#define __builtin_amdgcn_update_dpp emu_update_dpp
+inline int emu_readlane(int v, int src) { return emu_exchange(v, src); }
+#define __builtin_amdgcn_readlane emu_readlane
+inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
+inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; std::memcpy(&d, &b, 8); return d; }
+
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
