@@ -27,7 +27,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 int npl_for(int n_node) {
     int need = (n_node + 63) / 64;
-    const int choices[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const int choices[] = {1, 2, 4, 8, 16};
     for (int c : choices) if (c >= need) return c;
     return -1;
 }
@@ -44,6 +44,7 @@ struct wrsn_handle {
     std::vector<void*> allocs;
     int32_t* d_agent_tmp;      // [B] agent ids for rendering when the caller passes no agent_id output
     int32_t* d_reset_agent;    // [B] -1 everywhere: "agent" argument of a reset launch
+    WrsnDev* d_dev;            // device copy of `dev`: the environment kernels read it through the constant cache
 };
 
 namespace {
@@ -82,17 +83,16 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
                int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out) {
     dim3 grid(nenv), block(64);
     const int lds = h->lds_env;
-#define WRSN_LAUNCH(NPL_)                                                                                          \
-    hipLaunchKernelGGL(wrsn_env_kernel<NPL_>, grid, block, lds, h->stream, h->dev, mode, env0, agent_id, action, \
-                       auto_reset, mask, out)
+    const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
+#define WRSN_LAUNCH(NPL_)                                                                                              \
+    if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
+    else hipLaunchKernelGGL(wrsn_step_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                            auto_reset, mask, out)
     switch (h->npl) {
     case 1: WRSN_LAUNCH(1); break;
     case 2: WRSN_LAUNCH(2); break;
-    case 3: WRSN_LAUNCH(3); break;
     case 4: WRSN_LAUNCH(4); break;
-    case 6: WRSN_LAUNCH(6); break;
     case 8: WRSN_LAUNCH(8); break;
-    case 12: WRSN_LAUNCH(12); break;
     case 16: WRSN_LAUNCH(16); break;
     default: return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane");
     }
@@ -181,15 +181,17 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.nflags, B * NP))) break;
         if ((rc = alloc_node_arrays(h, &d.live))) break;
         if ((rc = alloc_node_arrays(h, &d.snap))) break;
-        if ((rc = dalloc(h, &d.counters, 4))) break;
+        if ((rc = dalloc(h, &d.counters, B * 25))) break;
         if ((rc = dalloc(h, &h->d_agent_tmp, B))) break;
         if ((rc = dalloc(h, &h->d_reset_agent, B))) break;
+        if ((rc = dalloc(h, &h->d_dev, 1))) break;
     } while (0);
     if (rc) { wrsn_destroy(h); return rc; }
     {
         std::vector<int32_t> neg(B, -1);
         if (hipMemcpy(h->d_reset_agent, neg.data(), B * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
     }
+    if (hipMemcpy(h->d_dev, &h->dev, sizeof(WrsnDev), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
     *out = h;
     return WRSN_OK;
 }
@@ -358,6 +360,9 @@ int wrsn_peek(wrsn_t* h, int32_t what, void* dst) {
             q[8] = dy[e].now; q[9] = dy[e].alive; q[10] = (double)dy[e].n_ticks; q[11] = (double)dy[e].n_exact;
             q[12] = (double)dy[e].n_events; q[13] = dy[e].last_minfit; q[14] = ec[e].n_edges; q[15] = ec[e].n_cover;
         }
+        return 0; }
+    case 10: {   // diagnostic builds (-DWRSN_PROFILE): int64 [B,25] per-phase cycle totals (+ whole kernel); zeros otherwise
+        HIPCHK(hipMemcpy(dst, d.counters, B * 25 * sizeof(int64_t), hipMemcpyDeviceToHost));
         return 0; }
     default: return fail(WRSN_ERR_ARG, "unknown peek selector");
     }

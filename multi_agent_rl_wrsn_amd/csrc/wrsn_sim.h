@@ -20,6 +20,27 @@
 #include "wrsn_types.h"
 
 #define WDEV __device__ __forceinline__
+// Diagnostic build only (-DWRSN_PROFILE, tools/build_profile.sh): per-phase cycle totals per environment.  Stamps go
+// to a buffer of their own (WrsnDev.counters) and no output is computed from them; the product build has none.
+#ifdef WRSN_PROFILE
+#define WRSN_PROF_DECL long long prof_[24]; long long prof_t_;
+#define WRSN_PROF_ZERO for (int q_ = 0; q_ < 24; ++q_) prof_[q_] = 0;
+#define WRSN_PROF_MARK(var) const long long var = clock64();
+#define WRSN_PROF_SPAN(slot, a, b) prof_[slot] += (b) - (a);
+#define WRSN_PROF_T0 const long long pt0_ = clock64();
+#define WRSN_PROF_ADD(slot) prof_[slot] += clock64() - pt0_;
+#define WRSN_PROF_CNT(slot, v) prof_[slot] += (v);
+#else
+#define WRSN_PROF_DECL
+#define WRSN_PROF_ZERO
+#define WRSN_PROF_T0
+#define WRSN_PROF_ADD(slot)
+#define WRSN_PROF_CNT(slot, v)
+#define WRSN_PROF_MARK(var)
+#define WRSN_PROF_SPAN(slot, a, b)
+#endif
+// profile slots: 0 scalar_run  1 grid_run  2 node_half(fast)  3 update_reward  4 exact_walk  5 rebuild_cache  6 set_levels
+//                7 min_fitness 8 precheck  9 conn_build  10 load  11 store  12 #services  13 #fused seconds  14 #jumped seconds  15 #generic items
 #define WRSN_URGENT 0
 #define WRSN_NORMAL 1
 #define WRSN_INF (__builtin_inf())
@@ -73,6 +94,28 @@ WDEV void wv_sum2(double& a, double& b) {                   // two independent s
     a += dpp_f64<WRSN_DPP_ROW_BCAST31, 0xc>(0.0, a); b += dpp_f64<WRSN_DPP_ROW_BCAST31, 0xc>(0.0, b);
     a = lane63_f64(a); b = lane63_f64(b);
 }
+template <int CTRL, int ROW_MASK>
+WDEV float dpp_f32(float ident, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+WDEV float wv_sumf(float v) {
+    v += dpp_f32<WRSN_DPP_QP_1032, 0xf>(0.f, v);
+    v += dpp_f32<WRSN_DPP_QP_2301, 0xf>(0.f, v);
+    v += dpp_f32<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(0.f, v);
+    v += dpp_f32<WRSN_DPP_ROW_MIRROR, 0xf>(0.f, v);
+    v += dpp_f32<WRSN_DPP_ROW_BCAST15, 0xa>(0.f, v);
+    v += dpp_f32<WRSN_DPP_ROW_BCAST31, 0xc>(0.f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+WDEV void wv_sum2f(float& a, float& b) {
+    a += dpp_f32<WRSN_DPP_QP_1032, 0xf>(0.f, a); b += dpp_f32<WRSN_DPP_QP_1032, 0xf>(0.f, b);
+    a += dpp_f32<WRSN_DPP_QP_2301, 0xf>(0.f, a); b += dpp_f32<WRSN_DPP_QP_2301, 0xf>(0.f, b);
+    a += dpp_f32<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(0.f, a); b += dpp_f32<WRSN_DPP_ROW_HALF_MIRROR, 0xf>(0.f, b);
+    a += dpp_f32<WRSN_DPP_ROW_MIRROR, 0xf>(0.f, a); b += dpp_f32<WRSN_DPP_ROW_MIRROR, 0xf>(0.f, b);
+    a += dpp_f32<WRSN_DPP_ROW_BCAST15, 0xa>(0.f, a); b += dpp_f32<WRSN_DPP_ROW_BCAST15, 0xa>(0.f, b);
+    a += dpp_f32<WRSN_DPP_ROW_BCAST31, 0xc>(0.f, a); b += dpp_f32<WRSN_DPP_ROW_BCAST31, 0xc>(0.f, b);
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63)); b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
 WDEV double wv_max(double v) {
     const double id = -WRSN_INF;
     v = fmax(v, dpp_f64<WRSN_DPP_QP_1032, 0xf>(id, v));
@@ -104,143 +147,212 @@ WDEV double dist2(double ax, double ay, double bx, double by) {
     return sqrt(dx * dx + dy * dy);
 }
 
+// 1/x to ~1e-15 relative: hardware estimate + two Newton steps (the consumers tolerate 1e-5)
+WDEV double fast_rcp(double x) {
+    double r = (double)(1.0f / (float)x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
 // ------------------------------------------------------------------ the per-environment simulator
 template <int NPL>
 struct Sim {
-    // identity / geometry
-    int env, lane, N, T, M, NP;
-    const WrsnEnvConst* ec;
-    const double *nx, *ny, *dbs, *nb_dist;
-    const int32_t *nb_off, *nb_idx, *tc_off, *tc_idx, *ncov, *nflags;
-    double *ring, *logbuf;
-    // LDS
-    double *sRR, *sU;
-    int32_t *sLS, *sRcv;
-    WrsnAgent* sAg;
-    WrsnThread* sTh;
-    double* sCT; int64_t* sCS; int32_t *sCA, *sCTr, *sCP;
-    double* sConnRate; int16_t* sConn;
-    int32_t* sReq;                     // mailbox: [0] request, [1] argument, [2] live charger-node connections, [3] flags
-    double* sReqD;                     //          [0] time limit, [1] now, [2] seq (as int64)
+    // identity / geometry.  Pointers are not kept as members: they are derived on demand from the device descriptor
+    // (scalar loads from the constant cache) and from the LDS base, which keeps the hot per-second loop small in
+    // registers.
+    int env, lane, N, T, M, NP, use_snap;
+    const WrsnDev* dp;
+    double* smem_;
     // node registers (per lane)
     double E[NPL], CS[NPL], d1[NPL], d2[NPL];
     unsigned am;                       // bit j: node j*64+lane alive
-    double cap, thr;
+    double cap, thr, max_time;
     // wave-uniform registers: identical in every lane.  `now` / `seq` are also advanced by lane 0 while it fires
     // charger events; they are re-broadcast through the mailbox at every hand-off.
     double opmax;
-    int64_t n_ticks, n_exact, n_events;
+    int64_t n_ticks, n_exact;
     int alive, levels_dirty, cache_dirty, irreg, ring_len, ring_head, safe_ticks, log_pending, err;
     double now; int64_t seq;
     double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;   // pending grid items
     int net_phase, net_active, node_phase, frozen, deaths_flag;
     double last_minfit;
-    // scalar registers: meaningful in lane 0 only
-    int L, pend, pend_idx;
+    WRSN_PROF_DECL
 
-    // -------------------------------------------------------------- setup of pointers
-    WDEV void bind(const WrsnDev& d, int env_, int lane_, double* smem) {
-        env = env_; lane = lane_; N = d.ec[env_].n_node; T = d.ec[env_].n_target; M = d.M; NP = d.NP;
-        ec = d.ec + env;
-        size_t nb = (size_t)env * NP;
-        nx = d.node_x + nb; ny = d.node_y + nb; dbs = d.dist_bs + nb;
-        nb_off = d.nb_off + (size_t)env * (NP + 1); nb_idx = d.nb_idx + (size_t)env * d.ECAP; nb_dist = d.nb_dist + (size_t)env * d.ECAP;
-        tc_off = d.tc_off + (size_t)env * (d.TP + 1); tc_idx = d.tc_idx + (size_t)env * d.CCAP;
-        ncov = d.ncov + nb; nflags = d.nflags + nb;
-        ring = d.live.ring + (size_t)env * WRSN_RING * NP; logbuf = d.live.logbuf + nb;
-        sRR = smem; sU = sRR + NP;
-        sLS = (int32_t*)(sU + 2 * NP); sRcv = sLS + NP;
-        sAg = (WrsnAgent*)(sRcv + NP);
-        sTh = (WrsnThread*)(sAg + M);
-        sCT = (double*)(sTh + 2 * M);
-        sCS = (int64_t*)(sCT + (M + 1));
-        sCA = (int32_t*)(sCS + (M + 1)); sCTr = sCA + (M + 1); sCP = sCTr + (M + 1);
-        uintptr_t p = (uintptr_t)(sCP + (M + 1)); p = (p + 7) & ~(uintptr_t)7;
-        sConnRate = (double*)p;
-        sConn = (int16_t*)(sConnRate + M * WRSN_CONN_CAP);
-        p = (uintptr_t)(sConn + M * WRSN_CONN_CAP); p = (p + 7) & ~(uintptr_t)7;
-        sReq = (int32_t*)p; sReqD = (double*)(sReq + 4);
-        cap = ec->capacity; thr = ec->threshold;
-        err = 0; pend = 0; pend_idx = 0; L = 0; deaths_flag = 0;
+    // lane-0 bookkeeping of the scalar event processor lives in LDS, not in registers
+    struct Scalar { double ev_time; int64_t ev_seq, n_events; int32_t L, pend, pend_idx, ev_valid, ev_kind, ev_idx, ev_prio, ev_uf; };
+    static_assert(sizeof(Scalar) == WRSN_LDS_SCALAR_BYTES, "wrsn_lds_bytes must match");
+
+    // ---- static topology / per-environment arrays in HBM
+    // per-environment constants are staged in LDS by bind(): a plain global load of them costs a full memory round
+    // trip (the backend cannot use scalar loads on mutable global memory)
+    WDEV const WrsnEnvConst* EC() const { return (const WrsnEnvConst*)(((uintptr_t)(SURAGENT() + M * WRSN_CONN_CAP) + 7) & ~(uintptr_t)7); }
+    WDEV const double* NX() const { return dp->node_x + (size_t)env * NP; }
+    WDEV const double* NY() const { return dp->node_y + (size_t)env * NP; }
+    WDEV const double* DBS() const { return dp->dist_bs + (size_t)env * NP; }
+    WDEV const int32_t* NB_OFF() const { return dp->nb_off + (size_t)env * (NP + 1); }
+    WDEV const int32_t* NB_IDX() const { return dp->nb_idx + (size_t)env * dp->ECAP; }
+    WDEV const double* NB_DIST() const { return dp->nb_dist + (size_t)env * dp->ECAP; }
+    WDEV const int32_t* TC_OFF() const { return dp->tc_off + (size_t)env * (dp->TP + 1); }
+    WDEV const int32_t* TC_IDX() const { return dp->tc_idx + (size_t)env * dp->CCAP; }
+    WDEV const int32_t* NCOV() const { return dp->ncov + (size_t)env * NP; }
+    WDEV const int32_t* NFLAGS() const { return dp->nflags + (size_t)env * NP; }
+    WDEV double* RING() const { return (use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP; }
+    WDEV double* LOGBUF() const { return (use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP; }
+    // ---- LDS carve-up (must match wrsn_lds_bytes)
+    WDEV double* SRR() const { return smem_; }
+    WDEV double* SU() const { return smem_ + NP; }
+    WDEV int32_t* SLS() const { return (int32_t*)(smem_ + 3 * NP); }
+    WDEV int32_t* SRCV() const { return SLS() + NP; }
+    WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(smem_ + 4 * NP); }
+    WDEV WrsnThread* STH() const { return (WrsnThread*)(SAG() + M); }
+    WDEV double* SCT() const { return (double*)(STH() + 2 * M); }
+    WDEV int64_t* SCS() const { return (int64_t*)(SCT() + (M + 1)); }
+    WDEV double* SCONNRATE() const { return (double*)(SCS() + (M + 1)); }
+    WDEV double* SURRATE() const { return SCONNRATE() + M * WRSN_CONN_CAP; }
+    WDEV double* SURACC() const { return SURRATE() + M * WRSN_CONN_CAP; }
+    WDEV double* SREQD() const { return SURACC() + M * WRSN_CONN_CAP; }                 // [0] time limit, [1] now, [2] seq (as int64), [3] spare
+    WDEV Scalar* SS() const { return (Scalar*)(SREQD() + 4); }
+    WDEV int32_t* SREQ() const { return (int32_t*)(SS() + 1); }                           // [0] request, [1] argument, [2] live connections, [3] flags
+    WDEV int32_t* SCA() const { return SREQ() + 4; }
+    WDEV int32_t* SCTR() const { return SCA() + (M + 1); }
+    WDEV int32_t* SCP() const { return SCTR() + (M + 1); }
+    WDEV int32_t* SURN() const { return SCP() + (M + 1); }
+    WDEV int16_t* SCONN() const { return (int16_t*)(SURN() + 1); }
+    WDEV int16_t* SURIDX() const { return SCONN() + M * WRSN_CONN_CAP; }
+    WDEV int16_t* SURAGENT() const { return SURIDX() + M * WRSN_CONN_CAP; }
+
+    // -------------------------------------------------------------- setup
+    WDEV void bind(const WrsnDev* dp_, int env_, int lane_, double* smem) {
+        dp = dp_; env = env_; lane = lane_; M = dp_->M; NP = dp_->NP;
+        smem_ = smem; use_snap = 0;
+        {   // stage the constants of this environment in LDS
+            const uint64_t* g = (const uint64_t*)(dp_->ec + env_); uint64_t* l = (uint64_t*)EC();
+            for (int w = lane; w < (int)(sizeof(WrsnEnvConst) / 8); w += 64) l[w] = g[w];
+        }
+        __syncthreads();
+        N = EC()->n_node; T = EC()->n_target;
+        cap = EC()->capacity; thr = EC()->threshold; max_time = EC()->max_time;
+        err = 0; deaths_flag = 0;
+        if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
+    }
+
+    // -------------------------------------------------------------- neighbour ids of the lane's nodes (static topology)
+    // 8 ids of 16 bit per node slot (0xFFFF = none), id order; loaded only by the two routines that sweep the graph.
+    static constexpr bool kNbReg = (NPL <= 6);
+    struct NbRegs { uint32_t p[kNbReg ? NPL : 1][4]; unsigned ovf; };
+    WDEV void load_neighbors(NbRegs& nb) const {
+        nb.ovf = 0;
+        if (kNbReg) {
+            const int32_t* off = NB_OFF(); const int32_t* idx = NB_IDX();
+#pragma unroll
+            for (int j = 0; j < (kNbReg ? NPL : 1); ++j) {
+                const int i = j * 64 + lane;
+                const int p0 = off[i], p1 = off[i + 1];
+                if (p1 - p0 > 8) nb.ovf |= 1u << j;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t lo = (p0 + 2 * w < p1) ? (uint32_t)idx[p0 + 2 * w] : 0xFFFFu;
+                    uint32_t hi = (p0 + 2 * w + 1 < p1) ? (uint32_t)idx[p0 + 2 * w + 1] : 0xFFFFu;
+                    nb.p[j][w] = lo | (hi << 16);
+                }
+            }
+        }
+    }
+    // visit the neighbours of own node slot j (node i)
+#define WRSN_FOR_NEIGHBORS(nbr, j, i, nbvar, body)                                                 \
+    if (kNbReg && !(((nbr).ovf >> (j)) & 1u)) {                                                    \
+        _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                                         \
+            const uint32_t pk_ = (nbr).p[kNbReg ? (j) : 0][w_];                                    \
+            { const int nbvar = (int)(pk_ & 0xFFFFu); if (nbvar != 0xFFFF) { body } }              \
+            { const int nbvar = (int)(pk_ >> 16); if (nbvar != 0xFFFF) { body } }                  \
+        }                                                                                          \
+    } else {                                                                                       \
+        const int32_t* off_ = NB_OFF(); const int32_t* idx_ = NB_IDX();                            \
+        for (int p_ = off_[i]; p_ < off_[(i) + 1]; ++p_) { const int nbvar = idx_[p_]; body }      \
     }
 
     // -------------------------------------------------------------- state load / store
-    WDEV void load(const WrsnNodeArrays& a) {
+    WDEV void load(const WrsnNodeArrays& a) { WRSN_PROF_T0
         size_t nb = (size_t)env * NP;
         am = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             E[j] = a.E[nb + i]; CS[j] = a.CS[nb + i]; d1[j] = a.d1[nb + i]; d2[j] = a.d2[nb + i];
-            sRR[i] = a.RR[nb + i];
-            int ls = a.ls[nb + i]; sLS[i] = ls; sRcv[i] = a.rcv[nb + i];
+            SRR()[i] = a.RR[nb + i];
+            int ls = a.ls[nb + i]; SLS()[i] = ls; SRCV()[i] = a.rcv[nb + i];
             am |= (unsigned)(ls & 1) << j;
         }
         const WrsnEnvDyn* dy = a.dyn + env;
         now = dy->now; seq = dy->seq; net_time = dy->net_time; net_seq = dy->net_seq; ur_time = dy->ur_time; ur_seq = dy->ur_seq;
         node_time = dy->node_time; node_seq = dy->node_seq; last_minfit = dy->last_minfit; opmax = dy->opmax;
-        n_ticks = dy->n_ticks; n_exact = dy->n_exact; n_events = dy->n_events;
+        n_ticks = dy->n_ticks; n_exact = dy->n_exact;
         net_phase = dy->net_phase; net_active = dy->net_active; node_phase = dy->node_phase; alive = dy->alive;
         levels_dirty = dy->levels_dirty; cache_dirty = dy->cache_dirty; irreg = dy->irreg; ring_len = dy->ring_len;
         ring_head = dy->ring_head; safe_ticks = dy->safe_ticks; frozen = dy->frozen;
         log_pending = dy->log_pending;
-        const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)sAg;
+        const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = ga[w];
-        const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)sTh;
+        const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)STH();
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = gt[w];
         const int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
         const double* gr = a.conn_rate + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { sConn[w] = gc[w]; sConnRate[w] = gr[w]; }
-        for (int w = lane; w <= M; w += 64) { sCTr[w] = 0; sCP[w] = 0; sCA[w] = 0; sCT[w] = 0; sCS[w] = 0; }
-        if (lane == 0) { sReq[0] = 0; sReq[1] = 0; sReq[2] = dy->n_connected; }
+        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { SCONN()[w] = gc[w]; SCONNRATE()[w] = gr[w]; }
+        for (int w = lane; w <= M; w += 64) { SCTR()[w] = 0; SCP()[w] = 0; SCA()[w] = 0; SCT()[w] = 0; SCS()[w] = 0; }
+        if (lane == 0) { SREQ()[0] = 0; SREQ()[1] = 0; SREQ()[2] = dy->n_connected; SS()->n_events = dy->n_events; SURN()[0] = 0; }
         __syncthreads();
+        WRSN_PROF_ADD(10)
     }
 
-    WDEV void store(const WrsnNodeArrays& a, int terminal_pending, int64_t n_steps_add) {
+    WDEV void store(const WrsnNodeArrays& a, int terminal_pending, int64_t n_steps_add) { WRSN_PROF_T0
         __syncthreads();
         size_t nb = (size_t)env * NP;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             a.E[nb + i] = E[j]; a.CS[nb + i] = CS[j]; a.d1[nb + i] = d1[j]; a.d2[nb + i] = d2[j];
-            a.RR[nb + i] = sRR[i]; a.ls[nb + i] = sLS[i]; a.rcv[nb + i] = sRcv[i];
+            a.RR[nb + i] = SRR()[i]; a.ls[nb + i] = SLS()[i]; a.rcv[nb + i] = SRCV()[i];
         }
         WrsnEnvDyn* dy = a.dyn + env;
         if (lane == 0) {
             dy->now = now; dy->seq = seq; dy->net_time = net_time; dy->net_seq = net_seq; dy->ur_time = ur_time; dy->ur_seq = ur_seq;
             dy->node_time = node_time; dy->node_seq = node_seq; dy->last_minfit = last_minfit; dy->opmax = opmax;
-            dy->n_ticks = n_ticks; dy->n_exact = n_exact; dy->n_events = n_events; dy->n_steps += n_steps_add;
+            dy->n_ticks = n_ticks; dy->n_exact = n_exact; dy->n_events = SS()->n_events; dy->n_steps += n_steps_add;
             dy->net_phase = net_phase; dy->net_active = net_active; dy->node_phase = node_phase; dy->alive = alive;
             dy->levels_dirty = levels_dirty; dy->cache_dirty = cache_dirty; dy->irreg = irreg; dy->ring_len = ring_len;
-            dy->ring_head = ring_head; dy->safe_ticks = safe_ticks; dy->frozen = frozen; dy->n_connected = sReq[2];
+            dy->ring_head = ring_head; dy->safe_ticks = safe_ticks; dy->frozen = frozen; dy->n_connected = SREQ()[2];
             dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending;
         }
-        uint64_t* ga = (uint64_t*)dy->ag; const uint64_t* la = (const uint64_t*)sAg;
+        uint64_t* ga = (uint64_t*)dy->ag; const uint64_t* la = (const uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) ga[w] = la[w];
-        uint64_t* gt = (uint64_t*)dy->th; const uint64_t* lt = (const uint64_t*)sTh;
+        uint64_t* gt = (uint64_t*)dy->th; const uint64_t* lt = (const uint64_t*)STH();
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) gt[w] = lt[w];
         int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
         double* gr = a.conn_rate + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { gc[w] = sConn[w]; gr[w] = sConnRate[w]; }
+        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { gc[w] = SCONN()[w]; gr[w] = SCONNRATE()[w]; }
+        WRSN_PROF_ADD(11)
     }
 
     WDEV double e_send(double d) const {                    // Node.py:114-115
         double dq = d * d;
-        return ((d <= ec->d0) ? (ec->et + ec->efs * dq) : (ec->et + ec->emp * (dq * dq))) * ec->package_size;
+        return ((d <= EC()->d0) ? (EC()->et + EC()->efs * dq) : (EC()->et + EC()->emp * (dq * dq))) * EC()->package_size;
     }
 
     // ============================================================== WAVE SERVICES (all 64 lanes, uniform control flow)
 
     // -------------------------------------------------------------- Network.setLevels + check_targets (Network.py:37-66, 84-85)
-    WDEV void set_levels() {
+    WDEV void set_levels() { WRSN_PROF_T0
+        NbRegs nbr; load_neighbors(nbr);
         int oldlv[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
-            int ls = sLS[i]; oldlv[j] = (ls >> 1) - 1;
+            int ls = SLS()[i]; oldlv[j] = (ls >> 1) - 1;
             int al = ls & 1;
-            int lv = (al && (nflags[i] & 1)) ? 1 : -1;
-            sLS[i] = ((lv + 1) << 1) | al;                   // own entry only
+            int lv = (al && (NFLAGS()[i] & 1)) ? 1 : -1;
+            SLS()[i] = ((lv + 1) << 1) | al;                   // own entry only
         }
         __syncthreads();
         for (int cur = 1; cur <= N; ++cur) {
@@ -248,74 +360,72 @@ struct Sim {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 int i = j * 64 + lane;
-                int ls = sLS[i]; newls[j] = ls;
+                int ls = SLS()[i]; newls[j] = ls;
                 if ((ls & 1) && (ls >> 1) == 0) {           // alive, level == -1
                     bool hit = false;
-                    for (int p = nb_off[i]; p < nb_off[i + 1]; ++p) {
-                        int l2 = sLS[nb_idx[p]];
-                        if ((l2 & 1) && ((l2 >> 1) - 1) == cur) { hit = true; break; }
-                    }
+                    WRSN_FOR_NEIGHBORS(nbr, j, i, nb, { const int l2 = SLS()[nb]; if ((l2 & 1) && ((l2 >> 1) - 1) == cur) hit = true; })
                     if (hit) { newls[j] = ((cur + 2) << 1) | 1; ch = true; }
                 }
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) sLS[j * 64 + lane] = newls[j];
+            for (int j = 0; j < NPL; ++j) SLS()[j * 64 + lane] = newls[j];
             __syncthreads();
             if (!wv_any(ch)) break;
         }
         bool changed = false;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) { int i = j * 64 + lane; if (((sLS[i] >> 1) - 1) != oldlv[j]) changed = true; }
+        for (int j = 0; j < NPL; ++j) { int i = j * 64 + lane; if (((SLS()[i] >> 1) - 1) != oldlv[j]) changed = true; }
         if (wv_any(changed)) cache_dirty = 1;
         bool bad = false;
         for (int t = lane; t < T; t += 64) {
             bool act = false;
-            for (int p = tc_off[t]; p < tc_off[t + 1]; ++p) if ((sLS[tc_idx[p]] >> 1) >= 2) act = true;   // covered by a reached node
+            for (int p = TC_OFF()[t]; p < TC_OFF()[t + 1]; ++p) if ((SLS()[TC_IDX()[p]] >> 1) >= 2) act = true;   // covered by a reached node
             if (!act) bad = true;
         }
         alive = wv_any(bad) ? 0 : 1;
         levels_dirty = 0;
+        WRSN_PROF_ADD(6)
     }
 
     // -------------------------------------------------------------- routing cache: receivers + per-tick drains
     // rcv_i = Node.find_receiver (Node.py:92-100) / base station (Node.py:108-111); c1/c2 = packets relayed per tick that
     // arrive before / after the node's own half-charge (sources with lower / higher id; Node.py:57-62 runs in id order).
-    WDEV void rebuild_cache() {
-        int32_t* c1 = (int32_t*)sU; int32_t* c2 = c1 + NP;
+    WDEV void rebuild_cache() { WRSN_PROF_T0
+        int32_t* c1 = (int32_t*)SU(); int32_t* c2 = c1 + NP;
         double es[NPL]; int rc[NPL];
-        const double er = ec->e_recv, com = ec->com_range;
+        const double er = EC()->e_recv, com = EC()->com_range;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
-            int ls = sLS[i]; int lvl = (ls >> 1) - 1;
+            int ls = SLS()[i]; int lvl = (ls >> 1) - 1;
             int r = -1; double dd = 0.0;
             if (ls & 1) {
-                if (dbs[i] > com) {
+                if (DBS()[i] > com) {
                     double bd = 0.0;
-                    for (int p = nb_off[i]; p < nb_off[i + 1]; ++p) {
-                        int nb = nb_idx[p]; int l2 = sLS[nb];
+                    for (int p = NB_OFF()[i]; p < NB_OFF()[i + 1]; ++p) {
+                        int nb = NB_IDX()[p]; int l2 = SLS()[nb];
                         if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) {
-                            double dist = nb_dist[p];
+                            double dist = NB_DIST()[p];
                             if (r < 0 || dist < bd) { r = nb; bd = dist; }
                         }
                     }
                     dd = bd;
-                } else { r = -2; dd = dbs[i]; }
+                } else { r = -2; dd = DBS()[i]; }
             }
             es[j] = (r != -1) ? e_send(dd) : 0.0; rc[j] = r;
-            sRcv[i] = r; c1[i] = 0; c2[i] = 0;
+            SRCV()[i] = r; c1[i] = 0; c2[i] = 0;
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             if (((am >> j) & 1u) && rc[j] >= 0) {
-                int n = ncov[i];
+                int n = NCOV()[i];
                 if (n > 0) {
                     int a = rc[j], guard = 0;
-                    while (a >= 0 && guard++ < N) { atomicAdd((i < a) ? &c1[a] : &c2[a], n); a = sRcv[a]; }
+                    while (a >= 0 && guard++ < N) { atomicAdd((i < a) ? &c1[a] : &c2[a], n); a = SRCV()[a]; }
                 }
             }
         }
@@ -326,94 +436,182 @@ struct Sim {
             int i = j * 64 + lane;
             if ((am >> j) & 1u) {
                 d1[j] = (double)c1[i] * (er + es[j]);
-                d2[j] = (double)c2[i] * (er + es[j]) + (double)ncov[i] * es[j];
+                d2[j] = (double)c2[i] * (er + es[j]) + (double)NCOV()[i] * es[j];
                 opm = fmax(opm, es[j]);
             } else { d1[j] = 0.0; d2[j] = 0.0; }
         }
         __syncthreads();
         opmax = wv_max(opm);
         cache_dirty = 0; irreg = WRSN_RING; safe_ticks = 0;
+        WRSN_PROF_ADD(5)
     }
 
-    // -------------------------------------------------------------- exact in-order packet walk of one k+0.5 instant
-    // (Node.py:57-62 + 102-132 literally, node-id order); only taken when a node may run out of energy this tick.
-    WDEV int live_receiver(int i, double* dd) {               // Node.find_receiver with live status
-        int lvl = (sLS[i] >> 1) - 1; int r = -1; double bd = 0.0;
-        for (int p = nb_off[i]; p < nb_off[i + 1]; ++p) {
-            int nb = nb_idx[p]; int l2 = sLS[nb];
-            if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) { double dist = nb_dist[p]; if (r < 0 || dist < bd) { r = nb; bd = dist; } }
+    // -------------------------------------------------------------- exact k+0.5 instant (a node may run dry this second)
+    // Node.py:57-62 + 102-132 process sources in node-id order; a packet is dropped and the node dies as soon as it cannot
+    // pay (Node.py:116-117, 126-127), which re-routes everything behind it.  As long as nobody can fail, the order inside a
+    // range of sources does not matter, so the second is replayed range by range in closed form (64 sources, then 8, then
+    // 1) and only the single source whose packets may hit a starving node is walked packet by packet on lane 0.
+    struct WalkRec { double E; int32_t rcv; float es; };      // LDS record for the packet-by-packet walk
+
+    WDEV int live_receiver(int i, double* dd) {               // Node.find_receiver with live status (stale levels)
+        int lvl = (SLS()[i] >> 1) - 1; int r = -1; double bd = 0.0;
+        for (int p = NB_OFF()[i]; p < NB_OFF()[i + 1]; ++p) {
+            int nb = NB_IDX()[p]; int l2 = SLS()[nb];
+            if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) { double dist = NB_DIST()[p]; if (r < 0 || dist < bd) { r = nb; bd = dist; } }
         }
         *dd = bd; return r;
     }
 
-    struct WalkRec { double E; int32_t rcv; float es; };      // one LDS read per visited node
+    // receivers + send cost of every alive node for the current (live status, last levels); returns max op cost
+    WDEV double walk_receivers(double (&es)[NPL]) {
+        const double com = EC()->com_range; double opm = EC()->e_recv;
+        __syncthreads();
+        int rc[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            int i = j * 64 + lane; int r = -1; double dd = 0.0;
+            if (SLS()[i] & 1) {
+                if (DBS()[i] > com) r = live_receiver(i, &dd); else { r = -2; dd = DBS()[i]; }
+            }
+            es[j] = (r != -1) ? e_send(dd) : 0.0; rc[j] = r;
+            opm = fmax(opm, es[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) SRCV()[j * 64 + lane] = rc[j];
+        __syncthreads();
+        return wv_max(opm);
+    }
 
-    WDEV void exact_walk(bool any_rr) {
-        WalkRec* rec = (WalkRec*)sU;                            // 16 B per node = the whole scratch
-        const double er = ec->e_recv;
-        double e_start[NPL];
+    // sources [a, b) in closed form.  Returns false (nothing changed) when some node might be unable to pay.
+    WDEV bool walk_range(int a, int b, const double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL], double margin) {
+        int32_t* c1 = (int32_t*)SU(); int32_t* c2 = c1 + NP;
+        const double er = EC()->e_recv;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) { c1[j * 64 + lane] = 0; c2[j * 64 + lane] = 0; }
+        __syncthreads();
+        for (int q0 = a; q0 < b; q0 += 64) {
+            const int q = q0 + lane;
+            if (q < b && (SLS()[q] & 1)) {
+                const int n = NCOV()[q]; int v = SRCV()[q], guard = 0;
+                if (n > 0) while (v >= 0 && guard++ < N) { atomicAdd((q < v) ? &c1[v] : &c2[v], n); v = SRCV()[v]; }
+            }
+        }
+        __syncthreads();
+        double en[NPL], gn[NPL]; bool unsafe = false;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = j * 64 + lane;
+            en[j] = E[j]; gn[j] = 0.0;
+            if ((am >> j) & 1u) {
+                const double per = er + es[j];
+                double e = E[j] - (double)c1[i] * per;           // sources with a lower id: before the node's own wake
+                if (c1[i] > 0 && e - thr < margin) unsafe = true;
+                if (i >= a && i < b) {                             // the node wakes inside this range (Node.py:60)
+                    double e2 = fmin(e + rrh[j], cap); gn[j] = e2 - e; e = e2;
+                    e -= (double)c2[i] * per + (double)NCOV()[i] * es[j];
+                    if ((c2[i] > 0 || (NCOV()[i] > 0 && es[j] > 0.0)) && e - thr < margin) unsafe = true;
+                } else if (c2[i] > 0) {
+                    e -= (double)c2[i] * per;
+                    if (e - thr < margin) unsafe = true;
+                }
+                en[j] = e;
+            }
+        }
+        const bool bad = wv_any(unsafe);
+        if (!bad) {
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) { E[j] = en[j]; gain[j] += gn[j]; }
+        }
+        __syncthreads();
+        return !bad;
+    }
+
+    // one source, packet by packet (lane 0), exactly as Node.send_package / receive_package; returns #deaths
+    WDEV int walk_single(int q, double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL]) {
+        WalkRec* rec = (WalkRec*)SU();
+        const double er = EC()->e_recv;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane;
-            e_start[j] = E[j];
-            double dd = 0.0; int r = sRcv[i];                    // send cost towards the cached receiver
-            if (r == -2) dd = dbs[i];
-            else if (r >= 0) { for (int p = nb_off[i]; p < nb_off[i + 1]; ++p) if (nb_idx[p] == r) { dd = nb_dist[p]; break; } }
-            WalkRec w; w.E = E[j]; w.rcv = r; w.es = (r != -1) ? (float)e_send(dd) : 0.0f;
+            const int i = j * 64 + lane;
+            if (i == q && ((am >> j) & 1u)) { double e2 = fmin(E[j] + rrh[j], cap); gain[j] += e2 - E[j]; E[j] = e2; }   // the source wakes
+            WalkRec w; w.E = E[j]; w.rcv = SRCV()[i]; w.es = (float)es[j];
             rec[i] = w;
-            if (any_rr) logbuf[i] = 0.0;                        // becomes the half-charge actually gained at the node's wake
         }
         __syncthreads();
         if (lane == 0) {
             int deaths = 0;
-            for (int i = 0; i < N; ++i) {
-                if (!(sLS[i] & 1)) continue;
-                if (any_rr) {
-                    double e0 = rec[i].E, e1 = e0 + sRR[i] * 0.5;
-                    e1 = e1 < cap ? e1 : cap;
-                    rec[i].E = e1; logbuf[i] = e1 - e0;
-                }
-                const int nc = ncov[i];
+            if (SLS()[q] & 1) {
+                const int nc = NCOV()[q];
                 for (int p = 0; p < nc; ++p) {
-                    int cur = i;
+                    int cur = q;
                     for (int hop = 0; hop <= N; ++hop) {
                         WalkRec w = rec[cur];
-                        int r; double es;
-                        if (deaths == 0) { r = w.rcv; es = (double)w.es; }
-                        else if (nflags[cur] & 1) { r = -2; es = e_send(dbs[cur]); }
-                        else { double dd; r = live_receiver(cur, &dd); es = (r >= 0) ? e_send(dd) : 0.0; }
-                        if (r == -1) { if (w.E <= thr) { sLS[cur] &= ~1; deaths++; } break; }
-                        if (w.E - thr < es) { rec[cur].E = thr; sLS[cur] &= ~1; deaths++; break; }
-                        double e = w.E - es;
+                        int r; double esv;
+                        if (deaths == 0) { r = w.rcv; esv = (double)w.es; }
+                        else if (NFLAGS()[cur] & 1) { r = -2; esv = e_send(DBS()[cur]); }
+                        else { double dd; r = live_receiver(cur, &dd); esv = (r >= 0) ? e_send(dd) : 0.0; }
+                        if (r == -1) { if (w.E <= thr) { SLS()[cur] &= ~1; deaths++; } break; }
+                        if (w.E - thr < esv) { rec[cur].E = thr; SLS()[cur] &= ~1; deaths++; break; }
+                        double e = w.E - esv;
                         rec[cur].E = e;
-                        if (e <= thr) { sLS[cur] &= ~1; deaths++; }
+                        if (e <= thr) { SLS()[cur] &= ~1; deaths++; }
                         if (r == -2) break;
                         double e_r = rec[r].E;
-                        if (e_r - thr < er) { rec[r].E = thr; sLS[r] &= ~1; deaths++; break; }
+                        if (e_r - thr < er) { rec[r].E = thr; SLS()[r] &= ~1; deaths++; break; }
                         rec[r].E = e_r - er;
                         cur = r;
                     }
                 }
             }
+            SREQ()[1] = deaths;
         }
         __syncthreads();
-        bool died = false;
+        const int deaths = SREQ()[1];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane;
-            double e_end = rec[i].E;
-            if ((am >> j) & 1u) {
-                // every operation of a surviving node succeeded: log_energy = start + half-charge gained - end
-                double gain = any_rr ? logbuf[i] : 0.0;
-                logbuf[i] = e_start[j] + gain - e_end;
-                if (!(sLS[i] & 1)) { am &= ~(1u << j); CS[j] = 0.0; d1[j] = 0.0; d2[j] = 0.0; died = true; }   // Node.check_status
-            }
-            E[j] = e_end;
-        }
-        if (wv_any(died)) { cache_dirty = 1; levels_dirty = 1; deaths_flag = 1; }
-        irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++;
+        for (int j = 0; j < NPL; ++j) E[j] = rec[j * 64 + lane].E;
         __syncthreads();
+        return deaths;
+    }
+
+    WDEV void exact_walk(const double (&rrh)[NPL], bool any_rr) { WRSN_PROF_T0
+        double es[NPL], gain[NPL], e_start[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) { e_start[j] = E[j]; gain[j] = 0.0; }
+        double margin = 0.0;
+        bool any_death = false, need_recv = true;
+        int a = 0, w = 64;
+        for (int guard = 0; a < N && guard < 4 * N + 64; ++guard) {
+            if (need_recv) { margin = 2.0 * walk_receivers(es); need_recv = false; }   // (re-)route for the live status
+            const int b = (a + w < N) ? a + w : N;
+            if (walk_range(a, b, es, rrh, gain, margin)) {
+                a = b;
+                if ((a & 63) == 0) w = 64; else if ((a & 7) == 0 && w < 8) w = 8;   // widen again at aligned boundaries
+            } else if (w > 1) {
+                w = (w == 64) ? 8 : 1;                       // somebody may starve in [a, b): look closer
+            } else {
+                const int deaths = walk_single(a, es, rrh, gain);
+                if (deaths > 0) {
+                    any_death = true; need_recv = true;      // everything behind the dead node is re-routed
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        const int i = j * 64 + lane;
+                        if (((am >> j) & 1u) && !(SLS()[i] & 1)) { am &= ~(1u << j); CS[j] = 0.0; d1[j] = 0.0; d2[j] = 0.0; }   // Node.check_status
+                    }
+                }
+                a += 1;
+                if ((a & 63) == 0) w = 64; else if ((a & 7) == 0) w = 8;
+            }
+        }
+        // log_energy of the second: every operation of a surviving node succeeded = start + half-charge gained - end
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) LOGBUF()[j * 64 + lane] = e_start[j] + gain[j] - E[j];
+        if (any_death) { cache_dirty = 1; levels_dirty = 1; deaths_flag = 1; }
+        irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++;
+        (void)any_rr;
+        __syncthreads();
+        WRSN_PROF_ADD(4)
     }
 
     // -------------------------------------------------------------- k+0.5: Node.operate first half for all nodes (Node.py:57-62)
@@ -422,6 +620,7 @@ struct Sim {
         bool fast = true;
         if (safe_ticks > 0) { safe_ticks--; }
         else {
+            WRSN_PROF_CNT(22, 1)
             bool trig = false; double mn = 1e30;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
@@ -447,7 +646,7 @@ struct Sim {
                 for (int j = 0; j < NPL; ++j) E[j] = (E[j] - d1[j]) - d2[j];
             }
             log_pending = 0;
-        } else exact_walk(any_rr);
+        } else exact_walk(rrh, any_rr);
     }
 
     // -------------------------------------------------------------- k+1.0: second half + consumption window (Node.py:65-77)
@@ -457,14 +656,15 @@ struct Sim {
             for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) E[j] = fmin(E[j] + rrh[j], cap);
         }
         if (irreg > 0) {
+            WRSN_PROF_CNT(23, 1)
             const int len = ring_len, head = ring_head;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 if ((am >> j) & 1u) {
                     int i = j * 64 + lane;
-                    double lg = log_pending ? logbuf[i] : (d1[j] + d2[j]);
-                    if (len < WRSN_RING) { ring[(size_t)len * NP + i] = lg; CS[j] = (CS[j] * len + lg) / (len + 1); }
-                    else { double old = ring[(size_t)head * NP + i]; CS[j] = (CS[j] * len - old + lg) / len; ring[(size_t)head * NP + i] = lg; }
+                    double lg = log_pending ? LOGBUF()[i] : (d1[j] + d2[j]);
+                    if (len < WRSN_RING) { RING()[(size_t)len * NP + i] = lg; CS[j] = (CS[j] * len + lg) / (len + 1); }
+                    else { double old = RING()[(size_t)head * NP + i]; CS[j] = (CS[j] * len - old + lg) / len; RING()[(size_t)head * NP + i] = lg; }
                 }
             }
             if (len < WRSN_RING) ring_len = len + 1; else ring_head = (head + 1) % WRSN_RING;
@@ -474,77 +674,95 @@ struct Sim {
     }
 
     WDEV double conn_rate_of(int m, int k, int i) const {    // alpha / (dist(node, charger) + beta)^2 (Node.py:137, WRSN.py:122)
-        if (sAg[m].loc[0] == sAg[m].conn_loc[0] && sAg[m].loc[1] == sAg[m].conn_loc[1]) return sConnRate[m * WRSN_CONN_CAP + k];
-        double dd = dist2(nx[i], ny[i], sAg[m].loc[0], sAg[m].loc[1]) + ec->beta;
-        return ec->alpha / (dd * dd);
+        if (SAG()[m].loc[0] == SAG()[m].conn_loc[0] && SAG()[m].loc[1] == SAG()[m].conn_loc[1]) return SCONNRATE()[m * WRSN_CONN_CAP + k];
+        double dd = dist2(NX()[i], NY()[i], SAG()[m].loc[0], SAG()[m].loc[1]) + EC()->beta;
+        return EC()->alpha / (dd * dd);
     }
 
     // -------------------------------------------------------------- WRSN.update_reward (WRSN.py:100-127)
     // priorities: p = CS / (E - thr + 1e-9) (0 for dead nodes), standardised (population std), exp, normalised.
-    // mean and variance come from one fused pair of sums; the node that owns a connected entry computes its own
-    // contribution and posts it to LDS, lane 0 adds them up in list order.
-    WDEV void update_reward() {
-        const double eps = 1e-9;
-        double x[NPL]; double s1 = 0.0, s2 = 0.0;
+    // Lane 0 keeps a list of (node, charger, rate) for the alive "charging" chargers (ur_build, rebuilt whenever a
+    // charger event or a node death changes it); the lane that owns a listed node adds its contribution to the
+    // entry's LDS accumulator every second, and the accumulators are folded into agents_exclusive_reward when the
+    // grid service ends (ur_flush).  No barrier, no cross-lane fetch per second.
+    WDEV void update_reward() { WRSN_PROF_T0
+        // float32 pipeline (v_rcp_f32 / v_sqrt_f32 / v_exp_f32, full-rate FMAs, half the DPP traffic): the priorities
+        // are ratios of order 1e-4..1e-2 and only enter the reward through 0.2 * excl / avg_nodes_agent; the
+        // deviation of excl from the float64 oracle stays below 1e-6 relative (tests/).
+        const float epsf = 1e-9f;
+        float x[NPL]; float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) { x[j] = ((am >> j) & 1u) ? (CS[j] / (E[j] - thr + eps)) : 0.0; s1 += x[j]; s2 += x[j] * x[j]; }
-        wv_sum2(s1, s2);
-        const double mean = s1 / N;
-        double var = s2 / N - mean * mean;
-        if (!(var > 0.0)) var = 0.0;
-        double sd = sqrt(var);
-        if (sd == 0.0) sd = eps;
-        double ex[NPL]; double es = 0.0;
+        for (int j = 0; j < NPL; ++j) { const float den = (float)(E[j] - thr) + epsf; x[j] = ((am >> j) & 1u) ? (float)CS[j] * __builtin_amdgcn_rcpf(den) : 0.f; s1 += x[j]; s2 = fmaf(x[j], x[j], s2); }
+        wv_sum2f(s1, s2);
+        const float invn = 1.0f / (float)N;
+        const float mean = s1 * invn;
+        float var = fmaf(-mean, mean, s2 * invn);
+        var = var > 0.f ? var : 0.f;
+        float sd = __builtin_sqrtf(var);
+        if (sd == 0.f) sd = epsf;
+        const float k2 = 1.44269504f * __builtin_amdgcn_rcpf(sd);     // exp(z) = 2^(z * log2 e)
+        float ex[NPL]; float es = 0.f;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) { ex[j] = (j * 64 + lane < N) ? (double)expf((float)((x[j] - mean) / sd)) : 0.0; es += ex[j]; }
-        double tot = wv_sum(es);
-        if (tot == 0.0) tot = eps;
-        const double a_b2 = ec->alpha / (ec->beta * ec->beta);
-        double* post = sU;                                   // [M][CONN_CAP] contributions
-        for (int m = 0; m < M; ++m) {
-            if (sAg[m].status == 0 || !sAg[m].type_charging) continue;
-            const int nc = sAg[m].n_conn;
-            for (int k = 0; k < nc; ++k) {
-                const int i = sConn[m * WRSN_CONN_CAP + k];
-                if (lane == (i & 63)) {
-                    const int jj = i >> 6;
-                    double Ei = E[0], Ci = CS[0], xi = ex[0];
+        for (int j = 0; j < NPL; ++j) { const float v = (j * 64 + lane < N) ? __builtin_amdgcn_exp2f((x[j] - mean) * k2) : 0.f; ex[j] = v; es += v; }
+        float tot = wv_sumf(es);
+        if (tot == 0.f) tot = epsf;
+        const double scale = 1.0 / ((double)tot * (EC()->alpha / (EC()->beta * EC()->beta)));
+        const int n = SURN()[0];
+        for (int k = 0; k < n; ++k) {
+            const int i = SURIDX()[k];
+            if (lane == (i & 63)) {
+                const int jj = i >> 6;
+                // value selects (not `if (j == jj) x = E[j]`): a pointer select would pin E[] / CS[] in scratch memory
+                double Ei = E[0], Ci = CS[0]; float xi = ex[0];
 #pragma unroll
-                    for (int j = 1; j < NPL; ++j) if (j == jj) { Ei = E[j]; Ci = CS[j]; xi = ex[j]; }
-                    double c = 0.0;
-                    if (sLS[i] & 1) {
-                        const double rate = conn_rate_of(m, k, i);
-                        const double e_no = fmin(Ei - Ci, thr);          // min / max as written (WRSN.py:123-124)
-                        const double e_with = fmax(Ei - Ci + rate, cap);
-                        c = (xi / tot) * (e_with - e_no) / a_b2;
-                    }
-                    post[m * WRSN_CONN_CAP + k] = c;
+                for (int j = 1; j < NPL; ++j) { const double ej = E[j], cj = CS[j]; const float xj = ex[j]; const bool hit = (j == jj); Ei = hit ? ej : Ei; Ci = hit ? cj : Ci; xi = hit ? xj : xi; }
+                if ((am >> jj) & 1u) {
+                    const double e_no = fmin(Ei - Ci, thr);              // min / max as written (WRSN.py:123-124)
+                    const double e_with = fmax(Ei - Ci + SURRATE()[k], cap);
+                    SURACC()[k] += (double)xi * (e_with - e_no) * scale;
                 }
             }
         }
+        WRSN_PROF_ADD(3)
+    }
+
+    // lane 0: the list update_reward iterates (alive chargers whose action type is "charging", their connected nodes)
+    WDEV void ur_build() {
+        int n = 0;
+        for (int m = 0; m < M; ++m) {
+            if (SAG()[m].status == 0 || !SAG()[m].type_charging) continue;
+            const int nc = SAG()[m].n_conn;
+            for (int k = 0; k < nc; ++k) {
+                const int i = SCONN()[m * WRSN_CONN_CAP + k];
+                if (!(SLS()[i] & 1)) continue;
+                SURIDX()[n] = (int16_t)i; SURAGENT()[n] = (int16_t)m; SURRATE()[n] = conn_rate_of(m, k, i); SURACC()[n] = 0.0; ++n;
+            }
+        }
+        SURN()[0] = n;
+    }
+
+    // fold the per-entry sums into agents_exclusive_reward (end of a grid service; all lanes call, lane 0 works)
+    WDEV void ur_flush() {
         __syncthreads();
         if (lane == 0) {
-            for (int m = 0; m < M; ++m) {
-                if (sAg[m].status == 0 || !sAg[m].type_charging) continue;
-                double incentive = 0.0; const int nc = sAg[m].n_conn;
-                for (int k = 0; k < nc; ++k) incentive += post[m * WRSN_CONN_CAP + k];
-                sAg[m].excl += incentive;
-            }
+            const int n = SURN()[0];
+            for (int k = 0; k < n; ++k) { SAG()[SURAGENT()[k]].excl += SURACC()[k]; SURACC()[k] = 0.0; }
         }
         __syncthreads();
     }
 
     // -------------------------------------------------------------- WRSN.get_network_fitness -> np.min (WRSN.py:188-220)
     // label-correcting widest path; the fixed point does not depend on visiting order, so relax in parallel.
-    WDEV double min_fitness() {
-        double* t = sU; double lt[NPL], tc[NPL];
+    WDEV double min_fitness() { WRSN_PROF_T0
+        NbRegs nbr; load_neighbors(nbr);
+        double* t = SU(); double lt[NPL], tc[NPL];
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             bool al = (am >> j) & 1u;
             lt[j] = al ? ((CS[j] == 0.0) ? WRSN_INF : (E[j] - thr) / CS[j]) : 0.0;
-            tc[j] = (al && (nflags[i] & 1)) ? lt[j] : -1.0;
+            tc[j] = (al && (NFLAGS()[i] & 1)) ? lt[j] : -1.0;
             t[i] = tc[j];
         }
         __syncthreads();
@@ -553,9 +771,9 @@ struct Sim {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 int i = j * 64 + lane;
-                if (((am >> j) & 1u) && !(nflags[i] & 1)) {
+                if (((am >> j) & 1u) && !(NFLAGS()[i] & 1)) {
                     double best = -1.0;
-                    for (int p = nb_off[i]; p < nb_off[i + 1]; ++p) { int nb = nb_idx[p]; if (sLS[nb] & 1) best = fmax(best, t[nb]); }
+                    WRSN_FOR_NEIGHBORS(nbr, j, i, nb, { best = fmax(best, t[nb]); })      // dead / unreached neighbours hold -1
                     double cand = fmin(lt[j], best);
                     if (cand > tc[j]) { tc[j] = cand; ch = true; }
                 }
@@ -569,24 +787,25 @@ struct Sim {
         double mn = WRSN_INF;
         for (int q = lane; q < T; q += 64) {
             double v = 0.0;
-            for (int p = tc_off[q]; p < tc_off[q + 1]; ++p) v = fmax(v, t[tc_idx[p]]);
+            for (int p = TC_OFF()[q]; p < TC_OFF()[q + 1]; ++p) v = fmax(v, t[TC_IDX()[p]]);
             mn = fmin(mn, v);
         }
         mn = wv_min(mn);
         __syncthreads();
+        WRSN_PROF_ADD(7)
         return mn;
     }
 
     // -------------------------------------------------------------- charger energy pre-check sum (MobileCharger.py:111-115)
     WDEV double precheck(int ti) {
-        const double dx = sTh[ti].phy[0], dy = sTh[ti].phy[1];
+        const double dx = STH()[ti].phy[0], dy = STH()[ti].phy[1];
         double part = 0.0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             if ((am >> j) & 1u) {
                 int i = j * 64 + lane;
-                double dis = dist2(dx, dy, nx[i], ny[i]);
-                if (dis <= ec->charging_range) part += ec->alpha / ((dis + ec->beta) * (dis + ec->beta));
+                double dis = dist2(dx, dy, NX()[i], NY()[i]);
+                if (dis <= EC()->charging_range) part += EC()->alpha / ((dis + EC()->beta) * (dis + EC()->beta));
             }
         }
         return wv_sum(part);
@@ -595,26 +814,26 @@ struct Sim {
     // -------------------------------------------------------------- connected_nodes of a charger (MobileCharger.py:55-58)
     // every node (alive or not) within charging range of the charger, id order; caches the connection rate
     WDEV void conn_build(int a) {
-        const double lx = sAg[a].loc[0], ly = sAg[a].loc[1];
+        const double lx = SAG()[a].loc[0], ly = SAG()[a].loc[1];
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
-            double dis = (i < N) ? dist2(nx[i], ny[i], lx, ly) : 0.0;
-            bool in = (i < N) && (dis <= ec->charging_range);
+            double dis = (i < N) ? dist2(NX()[i], NY()[i], lx, ly) : 0.0;
+            bool in = (i < N) && (dis <= EC()->charging_range);
             unsigned long long mk = __ballot(in);
             if (in) {
                 int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
                 if (pos < WRSN_CONN_CAP) {
-                    sConn[a * WRSN_CONN_CAP + pos] = (int16_t)i;
-                    double dd = dis + ec->beta;
-                    sConnRate[a * WRSN_CONN_CAP + pos] = ec->alpha / (dd * dd);
+                    SCONN()[a * WRSN_CONN_CAP + pos] = (int16_t)i;
+                    double dd = dis + EC()->beta;
+                    SCONNRATE()[a * WRSN_CONN_CAP + pos] = EC()->alpha / (dd * dd);
                 }
             }
             cnt += __popcll(mk);
         }
         if (cnt > WRSN_CONN_CAP) { err = -9; cnt = WRSN_CONN_CAP; }
-        if (lane == 0) { sAg[a].n_conn = cnt; sAg[a].conn_loc[0] = lx; sAg[a].conn_loc[1] = ly; }
+        if (lane == 0) { SAG()[a].n_conn = cnt; SAG()[a].conn_loc[0] = lx; SAG()[a].conn_loc[1] = ly; }
     }
 
     // ============================================================== GRID LOOP (all lanes, wave-uniform registers)
@@ -626,24 +845,27 @@ struct Sim {
     WDEV void grid_run(double t_limit, bool one, bool ur_flag) {
         deaths_flag = 0;
         // Node.energyRR only changes when lane 0 connects / disconnects a charger, i.e. between two grid services
-        const bool any_rr = sReq[2] > 0;
+        const bool any_rr = SREQ()[2] > 0;
         double rrh[NPL];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) rrh[j] = any_rr ? sRR[j * 64 + lane] * 0.5 : 0.0;
+        for (int j = 0; j < NPL; ++j) rrh[j] = any_rr ? SRR()[j * 64 + lane] * 0.5 : 0.0;
         for (long guard = 0; guard < 4000000L; ++guard) {
             if (frozen) break;
             int k = 1; double bt = ur_time; int64_t bs = ur_seq;
             if (node_time < bt || (node_time == bt && node_seq < bs)) { k = 2; bt = node_time; bs = node_seq; }
             if (net_active && (net_time < bt || (net_time == bt && net_seq < bs))) { k = 0; bt = net_time; bs = net_seq; }
             if (!one && !(bt < t_limit)) break;
-            // ---- canonical start of a second: setLevels @k+0.1 (no-op), nodes @k+0.5, reward/alive-check/nodes @k+1.0
+            bool do_ur = false, fused = false;
             const double kk = floor(bt);
-            if (!one && node_phase == 0 && (net_active ? (k == 0 && net_phase == 0) : (k == 2)) && !levels_dirty && ur_time == kk + 1.0) {
-                if (!any_rr && !ur_flag && irreg == 0 && !cache_dirty && !log_pending && safe_ticks > 0) {
-                    // nothing but the constant per-second drain happens: skip j whole seconds in closed form
+            // ---- canonical start of a second (setLevels@k+0.1 is a no-op, nodes@k+0.5, reward/alive-check/nodes@k+1.0) on
+            //      the steady path: nobody can run dry, the consumption window is uniform, the routing cache is valid
+            if (!one && irreg == 0 && !cache_dirty && !log_pending && safe_ticks > 0 && !levels_dirty && node_phase == 0 &&
+                (net_active ? (k == 0 && net_phase == 0) : (k == 2)) && ur_time == kk + 1.0) {
+                if (!any_rr && !ur_flag) {
+                    // nothing but the constant per-second drain: skip j whole seconds in closed form
                     double jf = floor(fmin(t_limit, kk + 1.0e6) - kk);
                     if (kk + jf >= t_limit) jf -= 1.0;
-                    if (net_active) { double jm = floor(fmin(ec->max_time, kk + 1.0e6) - kk); if (kk + jm >= ec->max_time) jm -= 1.0; jf = fmin(jf, jm); }
+                    if (net_active) { double jm = floor(fmin(max_time, kk + 1.0e6) - kk); if (kk + jm >= max_time) jm -= 1.0; jf = fmin(jf, jm); }
                     const int j = (int)fmin(jf, (double)safe_ticks);
                     if (j >= 1) {
                         const double dj = (double)j;
@@ -651,65 +873,78 @@ struct Sim {
                         for (int q = 0; q < NPL; ++q) E[q] -= dj * (d1[q] + d2[q]);
                         const double ke = kk + dj;
                         ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
-                        if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; n_events += 5 * (int64_t)j; }
-                        else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; n_events += 3 * (int64_t)j; }
+                        if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
+                        else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; }
                         now = ke; n_ticks += j; safe_ticks -= j;
+                        WRSN_PROF_CNT(14, j)
                         continue;
                     }
-                }
-                if (kk + 1.0 < t_limit && (!net_active || kk + 1.0 < ec->max_time)) {
-                    // one whole second, straight-line: the five items keep their order, nothing can interleave
-                    now = kk + 1.0 * 0.5;
-                    node_half(rrh, any_rr);
-                    if (deaths_flag) {                       // lane 0 must re-plan chargers before time moves on
-                        if (net_active) { const double t1 = kk + 1.0 / 10.0; net_phase = 1; net_time = t1 + 9.0 * 1.0 / 10.0; net_seq = seq++; n_events++; }
-                        node_phase = 1; node_time = now + 1.0 * 0.5; node_seq = seq++; n_events++;
-                        break;
+                } else if (kk + 1.0 < t_limit && (!net_active || kk + 1.0 < max_time)) {
+                    // one whole second, straight-line: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge
+                    fused = true;
+                    if (any_rr) {
+#pragma unroll
+                        for (int j = 0; j < NPL; ++j) { const double e = fmin(E[j] - d1[j] + rrh[j], cap) - d2[j]; E[j] = ((am >> j) & 1u) ? e : E[j]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NPL; ++j) E[j] = (E[j] - d1[j]) - d2[j];
                     }
                     now = kk + 1.0;
-                    if (ur_flag) update_reward();
-                    node_full(rrh, any_rr);
-                    ur_time = now + 1.0; node_time = now + 1.0 * 0.5;
-                    if (net_active) { net_time = now + 1.0 / 10.0; seq += 5; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; n_events += 5; }
-                    else { seq += 3; ur_seq = seq - 2; node_seq = seq - 1; n_events += 3; }
-                    continue;
+                    do_ur = ur_flag;
                 }
             }
-            // ---- generic path: one item
-            now = bt; n_events++;
-            if (k == 0) {
-                if (net_phase == 0) {                        // Network.py:75-78
-                    if (levels_dirty) set_levels();
-                    if (alive == 0) frozen = 1;              // terminal at the next return; node state is no longer observable
-                    net_phase = 1; net_time = now + 9.0 * 1.0 / 10.0; net_seq = seq++;
-                } else {                                     // Network.py:78-80
-                    if (alive == 0 || now >= ec->max_time) net_active = 0;
-                    else { net_phase = 0; net_time = now + 1.0 / 10.0; net_seq = seq++; }
+            if (!fused) {
+                // ---- one item (every O(N) routine has exactly one call site: the kernel has to fit the instruction cache)
+                WRSN_PROF_CNT(15, 1)
+                now = bt;
+                if (k == 0) {
+                    if (net_phase == 0) {                    // Network.py:75-78
+                        if (levels_dirty) set_levels();
+                        if (alive == 0) frozen = 1;          // terminal at the next return; node state is no longer observable
+                        net_phase = 1; net_time = now + 9.0 * 1.0 / 10.0; net_seq = seq++;
+                    } else {                                 // Network.py:78-80
+                        if (alive == 0 || now >= max_time) net_active = 0;
+                        else { net_phase = 0; net_time = now + 1.0 / 10.0; net_seq = seq++; }
+                    }
+                } else if (k == 1) {
+                    do_ur = ur_flag;
+                    ur_time = now + 1.0; ur_seq = seq++;
+                } else {
+                    if (node_phase == 0) { node_half(rrh, any_rr); node_phase = 1; } else { node_full(rrh, any_rr); node_phase = 0; }
+                    node_time = now + 1.0 * 0.5; node_seq = seq++;
                 }
-            } else if (k == 1) {
-                if (ur_flag) update_reward();
-                ur_time = now + 1.0; ur_seq = seq++;
-            } else {
-                if (node_phase == 0) { node_half(rrh, any_rr); node_phase = 1; } else { node_full(rrh, any_rr); node_phase = 0; }
-                node_time = now + 1.0 * 0.5; node_seq = seq++;
+            }
+            if (do_ur) update_reward();                      // the one call site
+            if (fused) {
+                if (any_rr) {
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) { const double e = fmin(E[j] + rrh[j], cap); E[j] = ((am >> j) & 1u) ? e : E[j]; }
+                }
+                ur_time = now + 1.0; node_time = now + 1.0 * 0.5;
+                if (net_active) { net_time = now + 1.0 / 10.0; seq += 5; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
+                else { seq += 3; ur_seq = seq - 2; node_seq = seq - 1; }
+                n_ticks++; safe_ticks--;
+                WRSN_PROF_CNT(13, 1)
+                continue;
             }
             if (one || deaths_flag) break;
         }
+        if (ur_flag) ur_flush();
     }
 
     // ============================================================== SCALAR EVENT PROCESSOR (lane 0 only)
 
-    WDEV void th_sched(int ti, int pc, int prio, double time) { sTh[ti].pc = pc; sTh[ti].prio = prio; sTh[ti].time = time; sTh[ti].seq = seq++; }
+    WDEV void th_sched(int ti, int pc, int prio, double time) { STH()[ti].pc = pc; STH()[ti].prio = prio; STH()[ti].time = time; STH()[ti].seq = seq++; }
 
     WDEV void mc_check_status(int a) {                       // MobileCharger.py:134-140
-        if (sAg[a].energy <= ec->mc_threshold) { sAg[a].status = 0; sAg[a].energy = ec->mc_threshold; }
+        if (SAG()[a].energy <= EC()->mc_threshold) { SAG()[a].status = 0; SAG()[a].energy = EC()->mc_threshold; }
     }
 
     WDEV bool agent_single(int a, int ti) const {            // no other live operate_step process acts on this charger
         for (int i = 0; i < 2 * M; ++i) {
             if (i == ti) continue;
-            int pc = sTh[i].pc;
-            if (pc != PC_NONE && pc != PC_FINISHED && sTh[i].agent == a) return false;
+            int pc = STH()[i].pc;
+            if (pc != PC_NONE && pc != PC_FINISHED && STH()[i].agent == a) return false;
         }
         return true;
     }
@@ -717,62 +952,87 @@ struct Sim {
     // ---- fast-forward: unit sub-steps of move() / charge() whose only effect is on the charger itself are kept
     // virtual and applied lazily (identical arithmetic, applied in order); the process resumes at the timeout of the
     // last unit sub-step.  Only taken in generic position; ties with the node grid use the per-sub-step path.
-    WDEV void ff_apply(int ti, double t, bool all) {
-        const int a = sTh[ti].agent;
-        int n = sTh[ti].ff_n; double ft = sTh[ti].ff_t;
-        if (sTh[ti].ff == 1) {
-            const double ux = sTh[ti].mvec[0] / sTh[ti].total_time * 1.0, uy = sTh[ti].mvec[1] / sTh[ti].total_time * 1.0;
-            const double de = ec->pm * 1.0 * ec->velocity;
-            double lx = sAg[a].loc[0], ly = sAg[a].loc[1], e = sAg[a].energy;
-            while (n > 0 && (all || ft + 1.0 <= t)) { lx = lx + ux; ly = ly + uy; e -= de; ft = ft + 1.0; --n; }
-            sAg[a].loc[0] = lx; sAg[a].loc[1] = ly; sAg[a].energy = e;
-        } else if (sTh[ti].ff == 2) {
-            const double cr = sAg[a].charging_rate;
-            double e = sAg[a].energy, c2 = sAg[a].cur[2], tmp = sTh[ti].tmp;
-            while (n > 0 && (all || ft + 1.0 <= t)) {
-                e = e - cr * 1.0; c2 = (c2 - 1.0) > 0.0 ? (c2 - 1.0) : 0.0; tmp -= 1.0; ft = ft + 1.0; --n;
-            }
-            sAg[a].energy = e; sAg[a].cur[2] = c2; sTh[ti].tmp = tmp;
+    // t + 1.0 + 1.0 ... (n times) with the same roundings as n successive additions: adding 1.0 is exact inside a
+    // binade, so only the (at most ~12) power-of-two crossings are done one by one
+    WDEV static double add_ones(double t, int n) {
+        while (n > 0) {
+            int ex; (void)frexp(t, &ex);                      // t in [2^(ex-1), 2^ex)
+            const double top = ldexp(1.0, ex);
+            double room = floor(top - t); if (top - t == room) room -= 1.0;   // additions that stay below 2^ex
+            if (t < 1.0 || room < 1.0) { t = t + 1.0; --n; continue; }
+            const int m = (double)n < room ? n : (int)room;
+            t = t + (double)m; n -= m;
         }
-        sTh[ti].ff_n = n; sTh[ti].ff_t = ft;
-        if (n == 0) sTh[ti].ff = 0;
+        return t;
+    }
+    // number of unit sub-steps (ends at ft+1, ft+2, ...) that have ended by time t, at most n
+    WDEV static int due_units(double ft, double t, int n) {
+        if (!(t >= ft + 1.0)) return 0;
+        double c = floor(t - ft);
+        int m = c < (double)n ? (int)c : n;
+        while (m > 0 && add_ones(ft, m) > t) --m;            // guard the rounding of the estimate
+        while (m < n && add_ones(ft, m + 1) <= t) ++m;
+        return m;
+    }
+
+    WDEV void ff_apply(int ti, double t, bool all) {
+        const int a = STH()[ti].agent;
+        int n = STH()[ti].ff_n; double ft = STH()[ti].ff_t;
+        if (STH()[ti].ff == 1) {
+            const double ux = STH()[ti].mvec[0] / STH()[ti].total_time * 1.0, uy = STH()[ti].mvec[1] / STH()[ti].total_time * 1.0;
+            const double de = EC()->pm * 1.0 * EC()->velocity;
+            // closed form of m identical unit sub-steps: positions / energy differ from the step-by-step sums by a few
+            // ulps (1e-13 relative), the time is accumulated exactly like successive `now + 1.0`
+            const int m = all ? n : due_units(ft, t, n);
+            const double dm = (double)m;
+            SAG()[a].loc[0] = SAG()[a].loc[0] + dm * ux; SAG()[a].loc[1] = SAG()[a].loc[1] + dm * uy; SAG()[a].energy = SAG()[a].energy - dm * de;
+            ft = add_ones(ft, m); n -= m;
+        } else if (STH()[ti].ff == 2) {
+            const double cr = SAG()[a].charging_rate;
+            const int m = all ? n : due_units(ft, t, n);
+            const double dm = (double)m;
+            double c2 = SAG()[a].cur[2] - dm;                 // x - 1.0 is exact for x >= 1, so m unit steps == x - m
+            SAG()[a].energy = SAG()[a].energy - dm * (cr * 1.0); SAG()[a].cur[2] = c2 > 0.0 ? c2 : 0.0; STH()[ti].tmp = STH()[ti].tmp - dm;
+            ft = add_ones(ft, m); n -= m;
+        }
+        STH()[ti].ff_n = n; STH()[ti].ff_t = ft;
+        if (n == 0) STH()[ti].ff = 0;
     }
 
     WDEV void ff_sync_all(double t) {
-        for (int i = 0; i < 2 * M; ++i) if (sTh[i].ff != 0 && sTh[i].pc != PC_NONE && sTh[i].pc != PC_FINISHED) ff_apply(i, t, false);
+        for (int i = 0; i < 2 * M; ++i) if (STH()[i].ff != 0 && STH()[i].pc != PC_NONE && STH()[i].pc != PC_FINISHED) ff_apply(i, t, false);
     }
 
     // a connected node died (or a second process now shares the charger): return to the per-sub-step path at the
     // sub-step in flight
     WDEV void ff_fallback(int ti) {
-        if (sTh[ti].ff == 0) return;
+        if (STH()[ti].ff == 0) return;
         ff_apply(ti, now, false);
-        if (sTh[ti].ff == 0) return;                         // everything virtual was already due: the resume event stands
-        const int kind = sTh[ti].ff;
-        sTh[ti].ff = 0; sTh[ti].ff_n = 0;
-        th_sched(ti, kind == 1 ? PC_MSTEP_TIMEOUT : PC_CSTEP_TIMEOUT, WRSN_NORMAL, sTh[ti].ff_t + 1.0);
+        if (STH()[ti].ff == 0) return;                         // everything virtual was already due: the resume event stands
+        const int kind = STH()[ti].ff;
+        STH()[ti].ff = 0; STH()[ti].ff_n = 0;
+        th_sched(ti, kind == 1 ? PC_MSTEP_TIMEOUT : PC_CSTEP_TIMEOUT, WRSN_NORMAL, STH()[ti].ff_t + 1.0);
     }
 
     WDEV void mc_move_loop(int ti) {                         // MobileCharger.py:85-94 from the top of `while True`
-        int a = sTh[ti].agent;
-        if (sTh[ti].moving_time <= 0.0) { th_sched(ti, PC_MOVE_DONE, WRSN_NORMAL, now); return; }
-        if (sAg[a].status == 0) { th_sched(ti, PC_MOVE_DEADWAIT, WRSN_NORMAL, now + sTh[ti].moving_time); return; }
-        double mt = dist2(sTh[ti].m_dest[0], sTh[ti].m_dest[1], sAg[a].loc[0], sAg[a].loc[1]) / ec->velocity;
-        sTh[ti].moving_time = mt;
+        int a = STH()[ti].agent;
+        if (STH()[ti].moving_time <= 0.0) { th_sched(ti, PC_MOVE_DONE, WRSN_NORMAL, now); return; }
+        if (SAG()[a].status == 0) { th_sched(ti, PC_MOVE_DEADWAIT, WRSN_NORMAL, now + STH()[ti].moving_time); return; }
+        double mt = dist2(STH()[ti].m_dest[0], STH()[ti].m_dest[1], SAG()[a].loc[0], SAG()[a].loc[1]) / EC()->velocity;
+        STH()[ti].moving_time = mt;
         double s = mt < 1.0 ? mt : 1.0;
-        const double pmv = ec->pm * ec->velocity;
-        double lim = (sAg[a].energy - ec->mc_threshold) / pmv;
-        sTh[ti].span = s < lim ? s : lim;
+        const double pmv = EC()->pm * EC()->velocity;
+        double lim = (SAG()[a].energy - EC()->mc_threshold) / pmv;
+        STH()[ti].span = s < lim ? s : lim;
         // fast-forward: a moving charger is observed by nobody until the run returns -- except through update_reward
         // when it is (stale) "charging" with connected nodes -- so whole-second sub-steps can stay virtual
-        if (mt > 3.0 && lim > 3.0 && !(sAg[a].type_charging && sAg[a].n_conn > 0) && agent_single(a, ti)) {
+        if (mt > 3.0 && lim > 3.0 && !(SAG()[a].type_charging && SAG()[a].n_conn > 0) && agent_single(a, ti)) {
             double nf = floor(fmin(mt, lim)) - 1.0;          // the remainder (> 1 s) and the energy margin go through the exact path
             if (nf > 100000.0) nf = 100000.0;
             int n = (int)nf;
             if (n >= 2) {
-                double t = now;
-                for (int q = 0; q < n; ++q) t = t + 1.0;     // same float accumulation as n successive timeouts
-                sTh[ti].span = 1.0; sTh[ti].ff = 1; sTh[ti].ff_n = n - 1; sTh[ti].ff_t = now;
+                const double t = add_ones(now, n);           // same float accumulation as n successive timeouts
+                STH()[ti].span = 1.0; STH()[ti].ff = 1; STH()[ti].ff_n = n - 1; STH()[ti].ff_t = now;
                 th_sched(ti, PC_MSTEP_TIMEOUT, WRSN_NORMAL, t);
                 return;
             }
@@ -782,46 +1042,46 @@ struct Sim {
 
     // Node.charger_connection / charger_disconnection over connected_nodes (Node.py:134-146); sign = +1 / -1
     WDEV int mc_connect(int a, double sign) {
-        const int nc = sAg[a].n_conn;
-        double cr = sAg[a].charging_rate; int cnt = 0;
+        const int nc = SAG()[a].n_conn;
+        double cr = SAG()[a].charging_rate; int cnt = 0;
         for (int k = 0; k < nc; ++k) {
-            int i = sConn[a * WRSN_CONN_CAP + k];
-            if (!(sLS[i] & 1)) continue;
+            int i = SCONN()[a * WRSN_CONN_CAP + k];
+            if (!(SLS()[i] & 1)) continue;
             double r = conn_rate_of(a, k, i);
-            sRR[i] += sign * r; cr += sign * r; cnt++;
+            SRR()[i] += sign * r; cr += sign * r; cnt++;
         }
-        sAg[a].charging_rate = cr;
-        if (sign > 0) { sAg[a].n_live = cnt; sReq[2] += cnt; }
-        else { sReq[2] -= sAg[a].n_live; sAg[a].n_live = 0; if (sReq[2] < 0) sReq[2] = 0; }
+        SAG()[a].charging_rate = cr;
+        if (sign > 0) { SAG()[a].n_live = cnt; SREQ()[2] += cnt; }
+        else { SREQ()[2] -= SAG()[a].n_live; SAG()[a].n_live = 0; if (SREQ()[2] < 0) SREQ()[2] = 0; }
         return cnt;
     }
 
     WDEV void mc_charge_loop(int ti) {                       // MobileCharger.py:59-69 from the top of `while True`
-        int a = sTh[ti].agent;
-        if (sTh[ti].tmp == 0.0) { th_sched(ti, PC_CHG_DONE, WRSN_NORMAL, now); return; }
-        if (sAg[a].status == 0) { sAg[a].cur[2] = 0.0; th_sched(ti, PC_CHG_DEADWAIT, WRSN_NORMAL, now + sTh[ti].tmp); return; }
-        double span = sTh[ti].tmp < 1.0 ? sTh[ti].tmp : 1.0;
-        if (sAg[a].charging_rate != 0.0) { double lim = (sAg[a].energy - ec->mc_threshold) / sAg[a].charging_rate; if (lim < span) span = lim; }
-        sTh[ti].cspan = span;
+        int a = STH()[ti].agent;
+        if (STH()[ti].tmp == 0.0) { th_sched(ti, PC_CHG_DONE, WRSN_NORMAL, now); return; }
+        if (SAG()[a].status == 0) { SAG()[a].cur[2] = 0.0; th_sched(ti, PC_CHG_DEADWAIT, WRSN_NORMAL, now + STH()[ti].tmp); return; }
+        double span = STH()[ti].tmp < 1.0 ? STH()[ti].tmp : 1.0;
+        if (SAG()[a].charging_rate != 0.0) { double lim = (SAG()[a].energy - EC()->mc_threshold) / SAG()[a].charging_rate; if (lim < span) span = lim; }
+        STH()[ti].cspan = span;
         // fast-forward: in generic position (no sub-step boundary on a node sampling instant k+0.5 / k+1.0) the
         // disconnect/reconnect pair of every boundary cancels, so the connection is made once and the whole-second
         // sub-steps stay virtual.  A node death or the charger running dry return to the exact path.
-        const double tmp = sTh[ti].tmp;
+        const double tmp = STH()[ti].tmp;
         const double fr = now - floor(now);
-        if (tmp > 3.0 && fr != 0.0 && fr != 0.5 && sAg[a].charging_rate == 0.0 && agent_single(a, ti)) {
+        if (tmp > 3.0 && fr != 0.0 && fr != 0.5 && SAG()[a].charging_rate == 0.0 && agent_single(a, ti)) {
             double nf = floor(tmp); if (nf == tmp) nf -= 1.0;          // unit sub-steps that are not the last one
             // rate this sub-step would connect with
-            double cr = 0.0; const int nc = sAg[a].n_conn;
-            for (int k = 0; k < nc; ++k) { int i = sConn[a * WRSN_CONN_CAP + k]; if (sLS[i] & 1) cr += conn_rate_of(a, k, i); }
-            if (cr > 0.0) { double ne = floor((sAg[a].energy - ec->mc_threshold) / cr) - 1.0; if (ne < nf) nf = ne; }
+            double cr = 0.0; const int nc = SAG()[a].n_conn;
+            for (int k = 0; k < nc; ++k) { int i = SCONN()[a * WRSN_CONN_CAP + k]; if (SLS()[i] & 1) cr += conn_rate_of(a, k, i); }
+            if (cr > 0.0) { double ne = floor((SAG()[a].energy - EC()->mc_threshold) / cr) - 1.0; if (ne < nf) nf = ne; }
             if (nf > 100000.0) nf = 100000.0;
             int n = (int)nf;
-            bool ok = n >= 2;
-            double t = now;
-            for (int q = 0; q < n && ok; ++q) { t = t + 1.0; double f2 = t - floor(t); if (f2 == 0.0 || f2 == 0.5) ok = false; }
+            // every boundary now + q keeps (up to the last bits) the fractional part of `now`; stay clear of the grid
+            bool ok = n >= 2 && fr > 1e-6 && fr < 1.0 - 1e-6 && (fr < 0.5 - 1e-6 || fr > 0.5 + 1e-6);
+            const double t = add_ones(now, ok ? n : 0);
             if (ok) {
                 mc_connect(a, 1.0);                          // charge_step #1 connects (MobileCharger.py:40-41)
-                sTh[ti].cspan = 1.0; sTh[ti].ff = 2; sTh[ti].ff_n = n - 1; sTh[ti].ff_t = now;
+                STH()[ti].cspan = 1.0; STH()[ti].ff = 2; STH()[ti].ff_n = n - 1; STH()[ti].ff_t = now;
                 th_sched(ti, PC_CSTEP_TIMEOUT, WRSN_NORMAL, t);
                 return;
             }
@@ -830,48 +1090,48 @@ struct Sim {
     }
 
     WDEV void cond_trigger(int j) {                          // Condition.succeed(): NORMAL at now
-        if (sCTr[j]) return;
-        sCTr[j] = 1; sCP[j] = 1; sCT[j] = now; sCS[j] = seq++;
+        if (SCTR()[j]) return;
+        SCTR()[j] = 1; SCP()[j] = 1; SCT()[j] = now; SCS()[j] = seq++;
     }
 
     WDEV void p_init_tail(int ti, double tmp) {              // MobileCharger.py:110, 116-121 / 128-130
-        const int a = sTh[ti].agent;
-        const double dx = sTh[ti].phy[0], dy = sTh[ti].phy[1], ct = sTh[ti].phy[2];
-        double used = dist2(dx, dy, sAg[a].loc[0], sAg[a].loc[1]) * ec->pm;
+        const int a = STH()[ti].agent;
+        const double dx = STH()[ti].phy[0], dy = STH()[ti].phy[1], ct = STH()[ti].phy[2];
+        double used = dist2(dx, dy, SAG()[a].loc[0], SAG()[a].loc[1]) * EC()->pm;
         used += tmp * ct;
-        used += dist2(dx, dy, ec->bs[0], ec->bs[1]) * ec->pm;
-        sAg[a].cur[0] = dx; sAg[a].cur[1] = dy; sAg[a].cur[2] = ct;
-        sAg[a].type_charging = 0;
-        if (used > sAg[a].energy - ec->mc_threshold - ec->mc_capacity / 200.0) { sTh[ti].stage = 0; sTh[ti].m_dest[0] = ec->bs[0]; sTh[ti].m_dest[1] = ec->bs[1]; }
-        else { sTh[ti].stage = 2; sTh[ti].m_dest[0] = dx; sTh[ti].m_dest[1] = dy; }
+        used += dist2(dx, dy, EC()->bs[0], EC()->bs[1]) * EC()->pm;
+        SAG()[a].cur[0] = dx; SAG()[a].cur[1] = dy; SAG()[a].cur[2] = ct;
+        SAG()[a].type_charging = 0;
+        if (used > SAG()[a].energy - EC()->mc_threshold - EC()->mc_capacity / 200.0) { STH()[ti].stage = 0; STH()[ti].m_dest[0] = EC()->bs[0]; STH()[ti].m_dest[1] = EC()->bs[1]; }
+        else { STH()[ti].stage = 2; STH()[ti].m_dest[0] = dx; STH()[ti].m_dest[1] = dy; }
         th_sched(ti, PC_MOVE_INIT, WRSN_URGENT, now);
     }
 
     // returns a wave request (REQ_PRECHECK / REQ_CONN) or 0
     WDEV int thread_fire(int ti) {
-        const int a = sTh[ti].agent;
-        if (sTh[ti].ff != 0) ff_apply(ti, now, true);        // the resume event: every virtual sub-step precedes it
-        switch (sTh[ti].pc) {
+        const int a = STH()[ti].agent;
+        if (STH()[ti].ff != 0) ff_apply(ti, now, true);        // the resume event: every virtual sub-step precedes it
+        switch (STH()[ti].pc) {
         case PC_P_INIT:                                      // MobileCharger.py:105-115: needs the O(N) sum
-            for (int i = 0; i < 2 * M; ++i) if (i != ti && sTh[i].agent == a) ff_fallback(i);   // a second process on this charger
-            pend = REQ_PRECHECK; pend_idx = ti; return REQ_PRECHECK;
+            for (int i = 0; i < 2 * M; ++i) if (i != ti && STH()[i].agent == a) ff_fallback(i);   // a second process on this charger
+            SS()->pend = REQ_PRECHECK; SS()->pend_idx = ti; return REQ_PRECHECK;
         case PC_MOVE_INIT: {                                 // MobileCharger.py:82-84
-            double mt = dist2(sTh[ti].m_dest[0], sTh[ti].m_dest[1], sAg[a].loc[0], sAg[a].loc[1]) / ec->velocity;
-            sTh[ti].moving_time = mt; sTh[ti].total_time = mt;
-            sTh[ti].mvec[0] = sTh[ti].m_dest[0] - sAg[a].loc[0]; sTh[ti].mvec[1] = sTh[ti].m_dest[1] - sAg[a].loc[1];
+            double mt = dist2(STH()[ti].m_dest[0], STH()[ti].m_dest[1], SAG()[a].loc[0], SAG()[a].loc[1]) / EC()->velocity;
+            STH()[ti].moving_time = mt; STH()[ti].total_time = mt;
+            STH()[ti].mvec[0] = STH()[ti].m_dest[0] - SAG()[a].loc[0]; STH()[ti].mvec[1] = STH()[ti].m_dest[1] - SAG()[a].loc[1];
             mc_move_loop(ti);
             break; }
         case PC_MSTEP_INIT:                                  // MobileCharger.py:76
-            th_sched(ti, PC_MSTEP_TIMEOUT, WRSN_NORMAL, now + sTh[ti].span);
+            th_sched(ti, PC_MSTEP_TIMEOUT, WRSN_NORMAL, now + STH()[ti].span);
             break;
         case PC_MSTEP_TIMEOUT:                               // MobileCharger.py:77-78
-            sAg[a].loc[0] = sAg[a].loc[0] + sTh[ti].mvec[0] / sTh[ti].total_time * sTh[ti].span;
-            sAg[a].loc[1] = sAg[a].loc[1] + sTh[ti].mvec[1] / sTh[ti].total_time * sTh[ti].span;
-            sAg[a].energy -= ec->pm * sTh[ti].span * ec->velocity;
+            SAG()[a].loc[0] = SAG()[a].loc[0] + STH()[ti].mvec[0] / STH()[ti].total_time * STH()[ti].span;
+            SAG()[a].loc[1] = SAG()[a].loc[1] + STH()[ti].mvec[1] / STH()[ti].total_time * STH()[ti].span;
+            SAG()[a].energy -= EC()->pm * STH()[ti].span * EC()->velocity;
             th_sched(ti, PC_MSTEP_DONE, WRSN_NORMAL, now);
             break;
         case PC_MSTEP_DONE:                                  // MobileCharger.py:95-96
-            sTh[ti].moving_time -= sTh[ti].span;
+            STH()[ti].moving_time -= STH()[ti].span;
             mc_check_status(a);
             mc_move_loop(ti);
             break;
@@ -879,12 +1139,12 @@ struct Sim {
             th_sched(ti, PC_MOVE_DONE, WRSN_NORMAL, now);
             break;
         case PC_MOVE_DONE:
-            if (sTh[ti].stage == 0) th_sched(ti, PC_RECH_INIT, WRSN_URGENT, now);                    // :123
-            else { sAg[a].type_charging = 1; th_sched(ti, PC_CHG_INIT, WRSN_URGENT, now); }         // :125-126 / :131-132
+            if (STH()[ti].stage == 0) th_sched(ti, PC_RECH_INIT, WRSN_URGENT, now);                    // :123
+            else { SAG()[a].type_charging = 1; th_sched(ti, PC_CHG_INIT, WRSN_URGENT, now); }         // :125-126 / :131-132
             break;
         case PC_RECH_INIT:                                   // MobileCharger.py:99-103
-            if (dist2(sAg[a].loc[0], sAg[a].loc[1], ec->bs[0], ec->bs[1]) <= ec->epsilon) {
-                sAg[a].loc[0] = ec->bs[0]; sAg[a].loc[1] = ec->bs[1]; sAg[a].energy = ec->mc_capacity;
+            if (dist2(SAG()[a].loc[0], SAG()[a].loc[1], EC()->bs[0], EC()->bs[1]) <= EC()->epsilon) {
+                SAG()[a].loc[0] = EC()->bs[0]; SAG()[a].loc[1] = EC()->bs[1]; SAG()[a].energy = EC()->mc_capacity;
             }
             th_sched(ti, PC_RECH_TIMEOUT, WRSN_NORMAL, now + 0.0);
             break;
@@ -892,26 +1152,26 @@ struct Sim {
             th_sched(ti, PC_RECH_DONE, WRSN_NORMAL, now);
             break;
         case PC_RECH_DONE:                                   // :124
-            sTh[ti].stage = 2; sTh[ti].m_dest[0] = sTh[ti].phy[0]; sTh[ti].m_dest[1] = sTh[ti].phy[1];
+            STH()[ti].stage = 2; STH()[ti].m_dest[0] = STH()[ti].phy[0]; STH()[ti].m_dest[1] = STH()[ti].phy[1];
             th_sched(ti, PC_MOVE_INIT, WRSN_URGENT, now);
             break;
         case PC_CHG_INIT:                                    // MobileCharger.py:52-58: needs the O(N) range scan
-            sTh[ti].tmp = sTh[ti].phy[2];
-            pend = REQ_CONN; pend_idx = ti; return REQ_CONN;
+            STH()[ti].tmp = STH()[ti].phy[2];
+            SS()->pend = REQ_CONN; SS()->pend_idx = ti; return REQ_CONN;
         case PC_CSTEP_INIT:                                  // MobileCharger.py:40-44
             mc_connect(a, 1.0);
-            th_sched(ti, PC_CSTEP_TIMEOUT, WRSN_NORMAL, now + sTh[ti].cspan);
+            th_sched(ti, PC_CSTEP_TIMEOUT, WRSN_NORMAL, now + STH()[ti].cspan);
             break;
         case PC_CSTEP_TIMEOUT: {                             // MobileCharger.py:45-50
-            sAg[a].energy = sAg[a].energy - sAg[a].charging_rate * sTh[ti].cspan;
-            double rem = sAg[a].cur[2] - sTh[ti].cspan;
-            sAg[a].cur[2] = rem > 0.0 ? rem : 0.0;
+            SAG()[a].energy = SAG()[a].energy - SAG()[a].charging_rate * STH()[ti].cspan;
+            double rem = SAG()[a].cur[2] - STH()[ti].cspan;
+            SAG()[a].cur[2] = rem > 0.0 ? rem : 0.0;
             mc_connect(a, -1.0);
-            sAg[a].charging_rate = 0.0;
+            SAG()[a].charging_rate = 0.0;
             th_sched(ti, PC_CSTEP_DONE, WRSN_NORMAL, now);
             break; }
         case PC_CSTEP_DONE:                                  // MobileCharger.py:70-72
-            sTh[ti].tmp -= sTh[ti].cspan;
+            STH()[ti].tmp -= STH()[ti].cspan;
             mc_check_status(a);
             mc_charge_loop(ti);
             break;
@@ -922,8 +1182,8 @@ struct Sim {
             th_sched(ti, PC_P_DONE, WRSN_NORMAL, now);
             break;
         case PC_P_DONE:                                      // the process event is processed: conditions of WRSN.step see it
-            sTh[ti].pc = PC_FINISHED;
-            for (int j = 1; j <= L; ++j) if (sAg[sCA[j - 1]].cur_thread == ti) cond_trigger(j);
+            STH()[ti].pc = PC_FINISHED;
+            for (int j = 1; j <= SS()->L; ++j) if (SAG()[SCA()[j - 1]].cur_thread == ti) cond_trigger(j);
             break;
         default: break;
         }
@@ -932,11 +1192,11 @@ struct Sim {
 
     WDEV int new_thread(int agent, double p0, double p1, double p2) {
         for (int i = 0; i < 2 * M; ++i) {
-            int pc = sTh[i].pc;
-            if (pc == PC_NONE || (pc == PC_FINISHED && sAg[sTh[i].agent].cur_thread != i)) {
-                sTh[i].agent = agent; sTh[i].phy[0] = p0; sTh[i].phy[1] = p1; sTh[i].phy[2] = p2;
-                sTh[i].stage = 0; sTh[i].moving_time = 0; sTh[i].total_time = 0; sTh[i].span = 0; sTh[i].tmp = 0; sTh[i].cspan = 0;
-                sTh[i].ff = 0; sTh[i].ff_n = 0; sTh[i].ff_t = 0;
+            int pc = STH()[i].pc;
+            if (pc == PC_NONE || (pc == PC_FINISHED && SAG()[STH()[i].agent].cur_thread != i)) {
+                STH()[i].agent = agent; STH()[i].phy[0] = p0; STH()[i].phy[1] = p1; STH()[i].phy[2] = p2;
+                STH()[i].stage = 0; STH()[i].moving_time = 0; STH()[i].total_time = 0; STH()[i].span = 0; STH()[i].tmp = 0; STH()[i].cspan = 0;
+                STH()[i].ff = 0; STH()[i].ff_n = 0; STH()[i].ff_t = 0;
                 th_sched(i, PC_P_INIT, WRSN_URGENT, now);
                 return i;
             }
@@ -945,7 +1205,7 @@ struct Sim {
     }
 
     WDEV bool agent_at_rest(int m) const {                   // WRSN.py:66 / :322
-        return dist2(sAg[m].loc[0], sAg[m].loc[1], sAg[m].cur[0], sAg[m].cur[1]) < 1e-9 && sAg[m].cur[2] == 0.0;
+        return dist2(SAG()[m].loc[0], SAG()[m].loc[1], SAG()[m].cur[0], SAG()[m].cur[1]) < 1e-9 && SAG()[m].cur[2] == 0.0;
     }
 
     // update_reward consumes the priorities only for alive chargers whose action type is "charging" and that have
@@ -954,9 +1214,9 @@ struct Sim {
     WDEV int ur_flags() const {
         int f = 0;
         for (int m = 0; m < M; ++m) {
-            if (sAg[m].status != 0 && sAg[m].type_charging && sAg[m].n_conn > 0) {
+            if (SAG()[m].status != 0 && SAG()[m].type_charging && SAG()[m].n_conn > 0) {
                 f |= 1;
-                for (int i = 0; i < 2 * M; ++i) if (sTh[i].agent == m && sTh[i].ff == 1 && sTh[i].pc != PC_NONE && sTh[i].pc != PC_FINISHED) f |= 2;
+                for (int i = 0; i < 2 * M; ++i) if (STH()[i].agent == m && STH()[i].ff == 1 && STH()[i].pc != PC_NONE && STH()[i].pc != PC_FINISHED) f |= 2;
             }
         }
         return f;
@@ -971,26 +1231,31 @@ struct Sim {
     // Fire charger / condition events in order until the wave has to do something: run the grid up to the next
     // event (REQ_GRID), an O(N) service (REQ_PRECHECK / REQ_CONN), or the run stops (REQ_STOP).
     WDEV int scalar_run(double svc, bool use_limit, double limit, int* arg, double* t_lim_out, int* flags_out) {
-        switch (pend) {                                      // finish the item that asked for the service
-        case REQ_PRECHECK: p_init_tail(pend_idx, svc); break;
-        case REQ_CONN: mc_charge_loop(pend_idx); break;
+        switch (SS()->pend) {                                      // finish the item that asked for the service
+        case REQ_PRECHECK: p_init_tail(SS()->pend_idx, svc); SS()->ev_valid = 0; break;
+        case REQ_CONN: mc_charge_loop(SS()->pend_idx); SS()->ev_valid = 0; break;
         case REQ_GRID:
             if (deaths_flag) {                               // a node died: chargers connected to it re-plan on the exact path
-                for (int i = 0; i < 2 * M; ++i) if (sTh[i].ff == 2 && sTh[i].pc != PC_NONE && sTh[i].pc != PC_FINISHED && sAg[sTh[i].agent].n_live > 0) ff_fallback(i);
+                for (int i = 0; i < 2 * M; ++i) if (STH()[i].ff == 2 && STH()[i].pc != PC_NONE && STH()[i].pc != PC_FINISHED && SAG()[STH()[i].agent].n_live > 0) ff_fallback(i);
+                SS()->ev_valid = 0;
             }
             break;
         default: break;
         }
-        pend = 0;
+        SS()->pend = 0;
         for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
-            int kind = -1, idx = 0; double bt = 0.0; int bp = 0; int64_t bs = 0;
-#define WRSN_CONSIDER(K, I, T_, P_, S_) if (kind < 0 || key_less((T_), (P_), (S_), bt, bp, bs)) { kind = (K); idx = (I); bt = (T_); bp = (P_); bs = (S_); }
-            for (int i = 0; i < 2 * M; ++i) {
-                int pc = sTh[i].pc;
-                if (pc != PC_NONE && pc != PC_FINISHED) { WRSN_CONSIDER(3, i, sTh[i].time, sTh[i].prio, sTh[i].seq) }
-            }
-            for (int j = 1; j <= L; ++j) if (sCP[j]) { WRSN_CONSIDER(4, j, sCT[j], WRSN_NORMAL, sCS[j]) }
+            if (!SS()->ev_valid) {                                 // charger / condition state only changes when one of them fires
+                int kind_ = -1, idx_ = 0; double bt_ = 0.0; int bp_ = 0; int64_t bs_ = 0;
+#define WRSN_CONSIDER(K, I, T_, P_, S_) if (kind_ < 0 || key_less((T_), (P_), (S_), bt_, bp_, bs_)) { kind_ = (K); idx_ = (I); bt_ = (T_); bp_ = (P_); bs_ = (S_); }
+                for (int i = 0; i < 2 * M; ++i) {
+                    int pc = STH()[i].pc;
+                    if (pc != PC_NONE && pc != PC_FINISHED) { WRSN_CONSIDER(3, i, STH()[i].time, STH()[i].prio, STH()[i].seq) }
+                }
+                for (int j = 1; j <= SS()->L; ++j) if (SCP()[j]) { WRSN_CONSIDER(4, j, SCT()[j], WRSN_NORMAL, SCS()[j]) }
 #undef WRSN_CONSIDER
+                SS()->ev_kind = kind_; SS()->ev_idx = idx_; SS()->ev_time = bt_; SS()->ev_prio = bp_; SS()->ev_seq = bs_; SS()->ev_uf = ur_flags(); if (SS()->ev_uf & 1) ur_build(); else SURN()[0] = 0; SS()->ev_valid = 1;
+            }
+            const int kind = SS()->ev_kind, idx = SS()->ev_idx, bp = SS()->ev_prio; const double bt = SS()->ev_time; const int64_t bs = SS()->ev_seq;
             const bool have_ev = kind >= 0;
             // next grid item (wave-uniform registers; lane 0 holds the same copy)
             bool have_grid = !frozen;
@@ -1003,26 +1268,26 @@ struct Sim {
             double t_lim = have_ev ? bt : WRSN_INF;
             if (use_limit && limit < t_lim) t_lim = limit;
             if (have_grid && gt < t_lim) {
-                const int uf = ur_flags();
-                if (uf & 2) { ff_sync_all(gt); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
+                const int uf = SS()->ev_uf;
+                if (uf & 2) { ff_sync_all(gt); ur_build(); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
                 else *arg = 0;
                 *t_lim_out = t_lim; *flags_out = uf & 1;
-                pend = REQ_GRID; return REQ_GRID;
+                SS()->pend = REQ_GRID; return REQ_GRID;
             }
             if (use_limit && !(have_ev && bt < limit)) { now = limit; return REQ_STOP; }
             if (have_grid && have_ev && gt == bt && key_less(gt, WRSN_NORMAL, gs, bt, bp, bs)) {
-                const int uf = ur_flags();
-                if (uf & 2) ff_sync_all(gt);
+                const int uf = SS()->ev_uf;
+                if (uf & 2) { ff_sync_all(gt); ur_build(); }
                 *arg = 1; *t_lim_out = t_lim; *flags_out = uf & 1;
-                pend = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
+                SS()->pend = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
             }
-            now = bt; n_events++;
+            now = bt; SS()->n_events++; SS()->ev_valid = 0;
             if (kind == 3) {
                 int r = thread_fire(idx);
-                if (r) { *arg = (r == REQ_CONN) ? sTh[idx].agent : idx; return r; }
+                if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; return r; }
             } else {
-                sCP[idx] = 0;
-                if (idx == L) return REQ_STOP;               // StopSimulation
+                SCP()[idx] = 0;
+                if (idx == SS()->L) return REQ_STOP;               // StopSimulation
                 cond_trigger(idx + 1);
             }
         }
@@ -1034,19 +1299,21 @@ struct Sim {
     WDEV void run(bool use_limit, double limit) {
         double svc = 0.0;
         for (long guard = 0; guard < 8000000L; ++guard) {
+            { WRSN_PROF_T0
             if (lane == 0) {
                 int arg = 0, fl = 0; double tl = 0.0;
                 int req = scalar_run(svc, use_limit, limit, &arg, &tl, &fl);
-                sReq[0] = req; sReq[1] = arg; sReq[3] = fl; sReqD[0] = tl; sReqD[1] = now; ((int64_t*)sReqD)[2] = seq;
+                SREQ()[0] = req; SREQ()[1] = arg; SREQ()[3] = fl; SREQD()[0] = tl; SREQD()[1] = now; ((int64_t*)SREQD())[2] = seq;
             }
             __syncthreads();
-            const int req = sReq[0], arg = sReq[1];
-            now = sReqD[1]; seq = ((const int64_t*)sReqD)[2];      // lane 0 advanced them while firing events
+            WRSN_PROF_ADD(0) WRSN_PROF_CNT(12, 1) }
+            const int req = SREQ()[0], arg = SREQ()[1];
+            now = SREQD()[1]; seq = ((const int64_t*)SREQD())[2];      // lane 0 advanced them while firing events
             if (req == REQ_STOP) break;
             switch (req) {
-            case REQ_GRID: grid_run(sReqD[0], arg != 0, sReq[3] != 0); break;
-            case REQ_PRECHECK: svc = precheck(arg); break;
-            case REQ_CONN: conn_build(arg); break;
+            case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], arg != 0, SREQ()[3] != 0); WRSN_PROF_ADD(1) } break;
+            case REQ_PRECHECK: { WRSN_PROF_T0 svc = precheck(arg); WRSN_PROF_ADD(8) } break;
+            case REQ_CONN: { WRSN_PROF_T0 conn_build(arg); WRSN_PROF_ADD(9) } break;
             default: break;
             }
             __syncthreads();
@@ -1057,92 +1324,106 @@ struct Sim {
     }
 };
 
-// ------------------------------------------------------------------ the environment kernel
-// mode WARMUP: t = 0 .. warm_up_time with no charger activity, snapshot into d.snap  (WRSN.py:41-64)
-// mode RESET : restore the snapshot into d.live and emit the reset request           (WRSN.py:66-75)
-// mode STEP  : WRSN.step                                                            (WRSN.py:289-330)
+// ------------------------------------------------------------------ the environment kernels
+// wrsn_warmup_kernel: t = 0 .. warm_up_time with no charger activity, snapshot into d.snap      (WRSN.py:41-64)
+// wrsn_step_kernel  : WRSN.step (WRSN.py:289-330); with `reset_call` (or auto-reset of a terminal environment) it
+//                     restores the snapshot into d.live and emits the reset request instead        (WRSN.py:66-75)
+// Two kernels so that the event machine and every O(N) routine are instantiated once per code object.
+#ifndef WRSN_WAVES_PER_SIMD
+#define WRSN_WAVES_PER_SIMD 1
+#endif
 template <int NPL>
-__global__ void __launch_bounds__(64) wrsn_env_kernel(WrsnDev d, int mode, int env0, const int32_t* __restrict__ agent_id,
-                                                      const double* __restrict__ action, int auto_reset,
-                                                      const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
+__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD) wrsn_warmup_kernel(const WrsnDev* __restrict__ dp, int env0) {
     extern __shared__ double smem[];
     const int env = env0 + blockIdx.x;
     const int lane = threadIdx.x;
-    if (env >= d.B) return;
+    if (env >= dp->B) return;
     Sim<NPL> s;
-    s.bind(d, env, lane, smem);
-    const WrsnEnvConst* ec = s.ec;
-
-    if (mode == WRSN_MODE_WARMUP) {
-        // NetworkIO.makeNetwork + Node.__init__ (Node.py:12-43) + t = 0 process start-up
-        s.am = 0;
+    s.bind(dp, env, lane, smem);
+    const WrsnEnvConst* ec = s.EC();
+    // NetworkIO.makeNetwork + Node.__init__ (Node.py:12-43) + t = 0 process start-up
+    s.am = 0;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane;
-            bool real = i < s.N;
-            s.E[j] = real ? ec->capacity : 0.0; s.CS[j] = 0.0; s.d1[j] = 0.0; s.d2[j] = 0.0;
-            int al = (real && ec->capacity > ec->threshold) ? 1 : 0;
-            s.sRR[i] = 0.0; s.sLS[i] = al; s.sRcv[i] = -1;
-            s.am |= (unsigned)al << j;
-        }
-        s.now = 0.0; s.seq = 0; s.last_minfit = 0.0; s.opmax = 0.0;
-        s.n_ticks = s.n_exact = s.n_events = 0;
-        s.alive = 1; s.levels_dirty = 1; s.cache_dirty = 1; s.irreg = WRSN_RING; s.ring_len = 0; s.ring_head = 0;
-        s.safe_ticks = 0; s.frozen = 0; s.log_pending = 0; s.L = 0;
-        uint64_t* la = (uint64_t*)s.sAg;
-        for (int w = lane; w < s.M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = 0;
-        uint64_t* lt = (uint64_t*)s.sTh;
-        for (int w = lane; w < 2 * s.M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = 0;
-        for (int w = lane; w < s.M * WRSN_CONN_CAP; w += 64) { s.sConn[w] = 0; s.sConnRate[w] = 0.0; }
-        for (int w = lane; w <= s.M; w += 64) { s.sCTr[w] = 0; s.sCP[w] = 0; s.sCA[w] = 0; s.sCT[w] = 0; s.sCS[w] = 0; }
-        __syncthreads();
-        if (lane == 0) {
-            s.sReq[0] = 0; s.sReq[1] = 0; s.sReq[2] = 0;
-            for (int m = 0; m < s.M; ++m) {                  // MobileCharger.__init__ + WRSN.py:44-49
-                s.sAg[m].loc[0] = ec->bs[0]; s.sAg[m].loc[1] = ec->bs[1]; s.sAg[m].energy = ec->mc_capacity; s.sAg[m].charging_rate = 0.0;
-                s.sAg[m].status = 1; s.mc_check_status(m);
-                s.sAg[m].type_charging = 0; s.sAg[m].n_conn = 0; s.sAg[m].cur_thread = -1; s.sAg[m].n_live = 0;
-                s.sAg[m].cur[0] = ec->bs[0]; s.sAg[m].cur[1] = ec->bs[1]; s.sAg[m].cur[2] = 0.0;
-                s.sAg[m].excl = 0.0; s.sAg[m].prev_minfit = 0.0;
-                s.sAg[m].conn_loc[0] = ec->bs[0]; s.sAg[m].conn_loc[1] = ec->bs[1];
-            }
-        }
-        // Network.operate -> timeout(0.1); update_reward body at t = 0 (no charger is charging) -> timeout(1); nodes -> timeout(0.5)
-        s.net_active = 1; s.net_phase = 0; s.net_time = s.now + 1.0 / 10.0; s.net_seq = s.seq++;
-        s.ur_time = s.now + 1.0; s.ur_seq = s.seq++;
-        s.node_phase = 0; s.node_time = s.now + 1.0 * 0.5; s.node_seq = s.seq++;
-        s.ring = d.snap.ring + (size_t)env * WRSN_RING * s.NP; s.logbuf = d.snap.logbuf + (size_t)env * s.NP;
-        __syncthreads();
-        s.run(true, ec->warm_up_time);                       // env.run(until=warm_up_time): stops before that instant's NORMAL events
-        double fit = s.min_fitness();
-        s.last_minfit = fit;
-        if (lane == 0) {
-            for (int m = 0; m < s.M; ++m) {                  // WRSN.py:59-64
-                s.sAg[m].action[0] = (ec->bs[0] - ec->frame[0]) / (ec->frame[1] - ec->frame[0]);
-                s.sAg[m].action[1] = (ec->bs[1] - ec->frame[2]) / (ec->frame[3] - ec->frame[2]);
-                s.sAg[m].action[2] = 0.0;
-                s.sAg[m].cur_thread = s.new_thread(m, s.sAg[m].cur[0], s.sAg[m].cur[1], s.sAg[m].cur[2]);
-                s.sAg[m].prev_minfit = fit; s.sAg[m].excl = 0.0;
-            }
-        }
-        s.store(d.snap, 0, 0);
-        return;
+    for (int j = 0; j < NPL; ++j) {
+        int i = j * 64 + lane;
+        bool real = i < s.N;
+        s.E[j] = real ? ec->capacity : 0.0; s.CS[j] = 0.0; s.d1[j] = 0.0; s.d2[j] = 0.0;
+        int al = (real && ec->capacity > ec->threshold) ? 1 : 0;
+        s.SRR()[i] = 0.0; s.SLS()[i] = al; s.SRCV()[i] = -1;
+        s.am |= (unsigned)al << j;
     }
+    s.now = 0.0; s.seq = 0; s.last_minfit = 0.0; s.opmax = 0.0;
+    s.n_ticks = s.n_exact = 0;
+    s.alive = 1; s.levels_dirty = 1; s.cache_dirty = 1; s.irreg = WRSN_RING; s.ring_len = 0; s.ring_head = 0;
+    s.safe_ticks = 0; s.frozen = 0; s.log_pending = 0;
+    uint64_t* la = (uint64_t*)s.SAG();
+    for (int w = lane; w < s.M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = 0;
+    uint64_t* lt = (uint64_t*)s.STH();
+    for (int w = lane; w < 2 * s.M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = 0;
+    for (int w = lane; w < s.M * WRSN_CONN_CAP; w += 64) { s.SCONN()[w] = 0; s.SCONNRATE()[w] = 0.0; }
+    for (int w = lane; w <= s.M; w += 64) { s.SCTR()[w] = 0; s.SCP()[w] = 0; s.SCA()[w] = 0; s.SCT()[w] = 0; s.SCS()[w] = 0; }
+    __syncthreads();
+    if (lane == 0) {
+        s.SREQ()[0] = 0; s.SREQ()[1] = 0; s.SREQ()[2] = 0; s.SURN()[0] = 0;
+        for (int m = 0; m < s.M; ++m) {                      // MobileCharger.__init__ + WRSN.py:44-49
+            s.SAG()[m].loc[0] = ec->bs[0]; s.SAG()[m].loc[1] = ec->bs[1]; s.SAG()[m].energy = ec->mc_capacity; s.SAG()[m].charging_rate = 0.0;
+            s.SAG()[m].status = 1; s.mc_check_status(m);
+            s.SAG()[m].type_charging = 0; s.SAG()[m].n_conn = 0; s.SAG()[m].cur_thread = -1; s.SAG()[m].n_live = 0;
+            s.SAG()[m].cur[0] = ec->bs[0]; s.SAG()[m].cur[1] = ec->bs[1]; s.SAG()[m].cur[2] = 0.0;
+            s.SAG()[m].excl = 0.0; s.SAG()[m].prev_minfit = 0.0;
+            s.SAG()[m].conn_loc[0] = ec->bs[0]; s.SAG()[m].conn_loc[1] = ec->bs[1];
+        }
+    }
+    // Network.operate -> timeout(0.1); update_reward body at t = 0 (no charger is charging) -> timeout(1); nodes -> timeout(0.5)
+    s.net_active = 1; s.net_phase = 0; s.net_time = s.now + 1.0 / 10.0; s.net_seq = s.seq++;
+    s.ur_time = s.now + 1.0; s.ur_seq = s.seq++;
+    s.node_phase = 0; s.node_time = s.now + 1.0 * 0.5; s.node_seq = s.seq++;
+    s.use_snap = 1;
+    __syncthreads();
+    s.run(true, ec->warm_up_time);                           // env.run(until=warm_up_time): stops before that instant's NORMAL events
+    double fit = s.min_fitness();
+    s.last_minfit = fit;
+    if (lane == 0) {
+        for (int m = 0; m < s.M; ++m) {                      // WRSN.py:59-64
+            s.SAG()[m].action[0] = (ec->bs[0] - ec->frame[0]) / (ec->frame[1] - ec->frame[0]);
+            s.SAG()[m].action[1] = (ec->bs[1] - ec->frame[2]) / (ec->frame[3] - ec->frame[2]);
+            s.SAG()[m].action[2] = 0.0;
+            s.SAG()[m].cur_thread = s.new_thread(m, s.SAG()[m].cur[0], s.SAG()[m].cur[1], s.SAG()[m].cur[2]);
+            s.SAG()[m].prev_minfit = fit; s.SAG()[m].excl = 0.0;
+        }
+    }
+    s.store(dp->snap, 0, 0);
+}
 
-    bool do_reset = (mode == WRSN_MODE_RESET);
-    if (mode == WRSN_MODE_RESET && env_mask && env_mask[env] == 0) return;
+template <int NPL>
+__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
+                                                       const double* __restrict__ action, int auto_reset,
+                                                       const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
+    extern __shared__ double smem[];
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (env >= dp->B) return;
+    bool do_reset = reset_call != 0;
+    if (reset_call && env_mask && env_mask[env] == 0) return;
     int aid = -1;
-    if (mode == WRSN_MODE_STEP) {
+    if (!reset_call) {
         aid = agent_id[env];
         if (aid == -2) return;
-        if (auto_reset && d.live.dyn[env].terminal_pending) do_reset = true;
+        if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
-
+    Sim<NPL> s;
+    s.bind(dp, env, lane, smem);
+#ifdef WRSN_PROFILE
+    for (int q_ = 0; q_ < 24; ++q_) s.prof_[q_] = 0;
+    const long long kt0_ = clock64();
+#endif
+    const WrsnEnvConst* ec = s.EC();
+    s.load(do_reset ? dp->snap : dp->live);
+    int terminal = 0;
     if (do_reset) {
-        s.load(d.snap);
-        const double* rs = d.snap.ring + (size_t)env * WRSN_RING * s.NP; double* rl = d.live.ring + (size_t)env * WRSN_RING * s.NP;
+        const double* rs = dp->snap.ring + (size_t)env * WRSN_RING * s.NP; double* rl = dp->live.ring + (size_t)env * WRSN_RING * s.NP;
         for (int w = lane; w < WRSN_RING * s.NP; w += 64) rl[w] = rs[w];
-        for (int w = lane; w < s.NP; w += 64) d.live.logbuf[(size_t)env * s.NP + w] = d.snap.logbuf[(size_t)env * s.NP + w];
+        for (int w = lane; w < s.NP; w += 64) dp->live.logbuf[(size_t)env * s.NP + w] = dp->snap.logbuf[(size_t)env * s.NP + w];
         if (lane == 0) {
             int agent = -1;
             for (int m = s.M - 1; m >= 0; --m) if (s.agent_at_rest(m)) agent = m;
@@ -1150,68 +1431,67 @@ __global__ void __launch_bounds__(64) wrsn_env_kernel(WrsnDev d, int mode, int e
             if (out.reward) out.reward[env] = 0.0;
             if (out.terminal) out.terminal[env] = (s.alive == 1) ? 0 : 1;
             if (out.now) out.now[env] = s.now;
-            if (out.status) out.status[env] = (mode == WRSN_MODE_STEP) ? 3 : 0;
+            if (out.status) out.status[env] = reset_call ? 0 : 3;
         }
-        s.store(d.live, 0, 0);
-        return;
-    }
-
-    // ---------------------------------------------------------- WRSN.step
-    s.load(d.live);
-    if (lane == 0) {
-        int st0 = 0;
-        if (aid >= 0 && aid < s.M) {
-            double act[3];
-            for (int k = 0; k < 3; ++k) { double v = action[(size_t)env * 3 + k]; act[k] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }   // np.clip (WRSN.py:299)
-            s.sAg[aid].action[0] = act[0]; s.sAg[aid].action[1] = act[1]; s.sAg[aid].action[2] = act[2];
-            double p0 = act[0] * (ec->frame[1] - ec->frame[0]) + ec->frame[0];      // translate (WRSN.py:95-98)
-            double p1 = act[1] * (ec->frame[3] - ec->frame[2]) + ec->frame[2];
-            double p2 = ec->charging_time_max * act[2];
-            int ti = s.new_thread(aid, p0, p1, p2);
-            if (ti < 0) s.err = -8; else s.sAg[aid].cur_thread = ti;
-            s.sAg[aid].prev_minfit = s.last_minfit;          // WRSN.py:304 (node state is unchanged since the last return)
-            s.sAg[aid].excl = 0.0;                           // WRSN.py:305
-        }
-        // general_process = net_process | p_a0 | p_a1 ... over chargers alive now (WRSN.py:307-310)
-        s.L = 0;
-        for (int m = 0; m < s.M; ++m) if (s.sAg[m].status != 0) { s.sCA[s.L] = m; s.L++; }
-        if (s.L == 0) st0 = 2;                               // reference: run() never returns; deliberate deviation
-        else {
-            for (int j = 1; j <= s.L; ++j) {                 // Condition.__init__ checks processed operands at once
-                int ti = s.sAg[s.sCA[j - 1]].cur_thread;
-                if (ti >= 0 && s.sTh[ti].pc == PC_FINISHED) s.cond_trigger(j);
+    } else {
+        // ------------------------------------------------------ WRSN.step
+        if (lane == 0) {
+            int st0 = 0;
+            if (aid >= 0 && aid < s.M) {
+                double act[3];
+                for (int k = 0; k < 3; ++k) { double v = action[(size_t)env * 3 + k]; act[k] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }   // np.clip (WRSN.py:299)
+                s.SAG()[aid].action[0] = act[0]; s.SAG()[aid].action[1] = act[1]; s.SAG()[aid].action[2] = act[2];
+                double p0 = act[0] * (ec->frame[1] - ec->frame[0]) + ec->frame[0];  // translate (WRSN.py:95-98)
+                double p1 = act[1] * (ec->frame[3] - ec->frame[2]) + ec->frame[2];
+                double p2 = ec->charging_time_max * act[2];
+                int ti = s.new_thread(aid, p0, p1, p2);
+                if (ti < 0) s.err = -8; else s.SAG()[aid].cur_thread = ti;
+                s.SAG()[aid].prev_minfit = s.last_minfit;      // WRSN.py:304 (node state is unchanged since the last return)
+                s.SAG()[aid].excl = 0.0;                       // WRSN.py:305
             }
+            // general_process = net_process | p_a0 | p_a1 ... over chargers alive now (WRSN.py:307-310)
+            s.SS()->L = 0;
+            for (int m = 0; m < s.M; ++m) if (s.SAG()[m].status != 0) { s.SCA()[s.SS()->L] = m; s.SS()->L++; }
+            if (s.SS()->L == 0) st0 = 2;                           // reference: run() never returns; deliberate deviation
+            else {
+                for (int j = 1; j <= s.SS()->L; ++j) {             // Condition.__init__ checks processed operands at once
+                    int ti = s.SAG()[s.SCA()[j - 1]].cur_thread;
+                    if (ti >= 0 && s.STH()[ti].pc == PC_FINISHED) s.cond_trigger(j);
+                }
+            }
+            s.SREQ()[3] = st0;
         }
-        s.sReq[3] = st0;
-    }
-    __syncthreads();
-    const int st0 = s.sReq[3];
-    int terminal = 0;
-    double fit = 0.0;
-    if (st0 == 2) terminal = 1;
-    else {
-        s.run(false, 0.0);                                   // env.run(until=general_process)
-        if (s.alive == 0) terminal = 1;                      // WRSN.py:312-320
-        else { fit = s.min_fitness(); s.last_minfit = fit; }
-    }
-    if (lane == 0) {
-        int agent = -1, status = st0; double reward = 0.0;
-        if (!terminal) {
-            for (int m = s.M - 1; m >= 0; --m) if (s.agent_at_rest(m)) agent = m;   // lowest id (WRSN.py:321-322)
-            if (agent >= 0) {                                // get_reward (WRSN.py:222-227)
-                double term_all = fit - s.sAg[agent].prev_minfit;
-                double term_excl = s.sAg[agent].excl / ec->avg_nodes_agent;
-                reward = (term_all * 0.8 + 0.2 * term_excl) / (ec->charging_time_max + ec->moving_time_max);
-            } else status = 1;                               // reference falls off the end and returns None
+        __syncthreads();
+        const int st0 = s.SREQ()[3];
+        double fit = 0.0;
+        if (st0 == 2) terminal = 1;
+        else {
+            s.run(false, 0.0);                               // env.run(until=general_process)
+            if (s.alive == 0) terminal = 1;                  // WRSN.py:312-320
+            else { fit = s.min_fitness(); s.last_minfit = fit; }
         }
-        if (s.err != 0) status = -4;
-        if (out.agent_id) out.agent_id[env] = agent;
-        if (out.reward) out.reward[env] = reward;
-        if (out.terminal) out.terminal[env] = (uint8_t)terminal;
-        if (out.now) out.now[env] = s.now;
-        if (out.status) out.status[env] = status;
+        if (lane == 0) {
+            int agent = -1, status = st0; double reward = 0.0;
+            if (!terminal) {
+                for (int m = s.M - 1; m >= 0; --m) if (s.agent_at_rest(m)) agent = m;   // lowest id (WRSN.py:321-322)
+                if (agent >= 0) {                            // get_reward (WRSN.py:222-227)
+                    double term_all = fit - s.SAG()[agent].prev_minfit;
+                    double term_excl = s.SAG()[agent].excl / ec->avg_nodes_agent;
+                    reward = (term_all * 0.8 + 0.2 * term_excl) / (ec->charging_time_max + ec->moving_time_max);
+                } else status = 1;                           // reference falls off the end and returns None
+            }
+            if (s.err != 0) status = -4;
+            if (out.agent_id) out.agent_id[env] = agent;
+            if (out.reward) out.reward[env] = reward;
+            if (out.terminal) out.terminal[env] = (uint8_t)terminal;
+            if (out.now) out.now[env] = s.now;
+            if (out.status) out.status[env] = status;
+        }
     }
-    s.store(d.live, terminal, 1);
+    s.store(dp->live, terminal, do_reset ? 0 : 1);
+#ifdef WRSN_PROFILE
+    if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
+#endif
 }
 
 // ------------------------------------------------------------------ topology kernel (one wave per environment)

@@ -89,18 +89,18 @@ struct WrsnStepOutDev {
     int32_t *agent_id; double *reward; uint8_t *terminal; double *now; float *obs; int32_t *status;
 };
 
+#define WRSN_LDS_SCALAR_BYTES 56
+// LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h)
 static inline int wrsn_lds_bytes(int NP, int M) {
     int b = 0;
-    b += NP * 8;                 // sRR
-    b += 2 * NP * 8;             // scratch (two double arrays / two int arrays)
-    b += NP * 4 * 2;             // sLS, sRcv
-    b += M * (int)sizeof(WrsnAgent);
-    b += 2 * M * (int)sizeof(WrsnThread);
-    b += (M + 1) * (8 + 8 + 4 + 4 + 4);
+    b += 4 * NP * 8;                                  // charging rate, 2 scratch arrays, level/alive + receiver words
+    b += M * (int)sizeof(WrsnAgent) + 2 * M * (int)sizeof(WrsnThread);
+    b += (M + 1) * (8 + 8);                           // condition times / seqs
+    b += 3 * M * WRSN_CONN_CAP * 8;                   // connection rates, reward-entry rates and accumulators
+    b += 4 * 8 + WRSN_LDS_SCALAR_BYTES + 4 * 4;       // mailbox doubles, scalar bookkeeping, mailbox ints
+    b += 3 * (M + 1) * 4 + 4;                         // condition agent / triggered / pending, reward-entry count
+    b += 3 * M * WRSN_CONN_CAP * 2;                   // connected-node ids, reward-entry node / charger
     b = (b + 7) & ~7;
-    b += M * WRSN_CONN_CAP * 8;  // cached connection rates
-    b += M * WRSN_CONN_CAP * 2;  // connected-node ids
-    b = (b + 7) & ~7;
-    b += 8 * 8;                  // service request mailbox
+    b += (int)sizeof(WrsnEnvConst);                   // constants of the environment
     return (b + 15) & ~15;
 }

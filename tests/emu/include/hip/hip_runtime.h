@@ -99,6 +99,13 @@ inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); retur
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; std::memcpy(&d, &b, 8); return d; }
 
+inline float emu_rcpf(float x) { return 1.0f / x; }
+#define __builtin_amdgcn_rcpf emu_rcpf
+inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline float emu_exp2f(float x) { return exp2f(x); }
+#define __builtin_amdgcn_exp2f emu_exp2f
+
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }

@@ -28,7 +28,7 @@ def test_header_and_binding_agree(hip_lib):
 def test_library_contains_gfx950_code_object():
     from multi_agent_rl_wrsn_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"wrsn_env_kernel" in blob
+    assert b"gfx950" in blob and b"wrsn_step_kernel" in blob and b"wrsn_warmup_kernel" in blob
 
 
 def test_struct_layouts_match_header(hip_lib):

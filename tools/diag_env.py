@@ -1,7 +1,10 @@
 """Diagnostic (not part of the product path): per-launch time of the environment kernel versus batch size / policy."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np, torch, ctypes as C
+from multi_agent_rl_wrsn_amd import _lib
+if os.environ.get("WRSN_DIAG_LIB"):       # diagnostic override (tools only): an alternative build of the HIP library
+    _lib._lib = _lib.bind(C.CDLL(os.environ["WRSN_DIAG_LIB"]))
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 
 def run(B, mode, steps=16, N=200, M=3):
@@ -28,7 +31,10 @@ def run(B, mode, steps=16, N=200, M=3):
     env.close()
 
 if __name__ == "__main__":
-    for B in (256, 1024, 4096):
-        run(B, "random")
-    run(4096, "nocharge")
-    run(4096, "shortcharge")
+    if os.environ.get("WRSN_DIAG_QUICK"):
+        run(256, "random"); run(4096, "random"); run(4096, "nocharge")
+    else:
+        for B in (256, 1024, 4096):
+            run(B, "random")
+        run(4096, "nocharge")
+        run(4096, "shortcharge")
