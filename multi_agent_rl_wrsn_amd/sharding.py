@@ -53,10 +53,10 @@ class RolloutStats:
         self.buf = torch.zeros((int(n_env_local), self.M + 3), dtype=torch.float64, device=device)
 
     def update(self, agent_id, reward, terminal, now):
+        """Accumulate one batch of returns.  Pure elementwise device ops (no index kernels, no host sync)."""
         t = self.torch
-        valid = agent_id >= 0
-        idx = agent_id.clamp(min=0).to(t.int64).unsqueeze(1)
-        self.buf[:, :self.M].scatter_add_(1, idx, (reward * valid).unsqueeze(1))
+        for m in range(self.M):
+            self.buf[:, m] += reward * (agent_id == m)
         term = terminal.to(t.float64)
         self.buf[:, self.M] += term
         self.buf[:, self.M + 1] += term * now
