@@ -47,7 +47,7 @@ typedef struct wrsn_cfg {
     int32_t n_node;           /* N: sensor nodes per environment (max over the batch)            */
     int32_t n_target;         /* T: targets per environment (max over the batch)                 */
     int32_t n_mc;             /* M: mobile chargers, `num_agent` (WRSN.py:26); 1..8               */
-    int32_t map_size;         /* G: observation is 4 x G x G (WRSN.py:27,31)                      */
+    int32_t map_size;         /* G: observation is 4 x G x G (WRSN.py:27,31); 4..128              */
     int32_t device;           /* HIP device ordinal                                               */
     int32_t max_degree;       /* average neighbour-list capacity per node (0 = default 24)        */
     int32_t max_cover;        /* average covered-target capacity per node (0 = default 8)         */

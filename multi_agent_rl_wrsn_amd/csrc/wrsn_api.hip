@@ -140,8 +140,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     if (!cfg || !out) return fail(WRSN_ERR_ARG, "null argument");
     *out = nullptr;
     if (cfg->n_env < 1 || cfg->n_node < 1 || cfg->n_target < 1 || cfg->n_mc < 1 || cfg->n_mc > WRSN_MAX_MC || cfg->map_size < 4 ||
-        cfg->map_size > 256 || cfg->n_node > 1024 || !(cfg->warm_up_time > 0.0))
-        return fail(WRSN_ERR_ARG, "wrsn_cfg out of range (n_mc 1..8, n_node 1..1024, map_size 4..256, warm_up_time > 0)");
+        cfg->map_size > 128 || cfg->n_node > 1024 || !(cfg->warm_up_time > 0.0))
+        return fail(WRSN_ERR_ARG, "wrsn_cfg out of range (n_mc 1..8, n_node 1..1024, map_size 4..128, warm_up_time > 0)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(WRSN_ERR_NO_DEVICE, "no HIP device: libwrsn_hip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(WRSN_ERR_ARG, "device ordinal out of range");

@@ -855,42 +855,31 @@ struct Sim {
             if (node_time < bt || (node_time == bt && node_seq < bs)) { k = 2; bt = node_time; bs = node_seq; }
             if (net_active && (net_time < bt || (net_time == bt && net_seq < bs))) { k = 0; bt = net_time; bs = net_seq; }
             if (!one && !(bt < t_limit)) break;
-            bool do_ur = false, fused = false;
+            bool do_ur = false, fused = false; int nrep = 0;
             const double kk = floor(bt);
             // ---- canonical start of a second (setLevels@k+0.1 is a no-op, nodes@k+0.5, reward/alive-check/nodes@k+1.0) on
             //      the steady path: nobody can run dry, the consumption window is uniform, the routing cache is valid
             if (!one && irreg == 0 && !cache_dirty && !log_pending && safe_ticks > 0 && !levels_dirty && node_phase == 0 &&
                 (net_active ? (k == 0 && net_phase == 0) : (k == 2)) && ur_time == kk + 1.0) {
-                if (!any_rr && !ur_flag) {
-                    // nothing but the constant per-second drain: skip j whole seconds in closed form
-                    double jf = floor(fmin(t_limit, kk + 1.0e6) - kk);
-                    if (kk + jf >= t_limit) jf -= 1.0;
-                    if (net_active) { double jm = floor(fmin(max_time, kk + 1.0e6) - kk); if (kk + jm >= max_time) jm -= 1.0; jf = fmin(jf, jm); }
-                    const int j = (int)fmin(jf, (double)safe_ticks);
-                    if (j >= 1) {
+                // whole seconds that fit before the next charger event / max_time and stay inside the safe horizon
+                double jf = floor(fmin(t_limit, kk + 1.0e6) - kk);
+                if (kk + jf >= t_limit) jf -= 1.0;
+                if (net_active) { double jm = floor(fmin(max_time, kk + 1.0e6) - kk); if (kk + jm >= max_time) jm -= 1.0; jf = fmin(jf, jm); }
+                const int j = (int)fmin(jf, (double)safe_ticks);
+                if (j >= 1) {
+                    if (!any_rr && !ur_flag) {
+                        // nothing but the constant per-second drain: closed form
                         const double dj = (double)j;
 #pragma unroll
                         for (int q = 0; q < NPL; ++q) E[q] -= dj * (d1[q] + d2[q]);
-                        const double ke = kk + dj;
-                        ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
-                        if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
-                        else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; }
-                        now = ke; n_ticks += j; safe_ticks -= j;
                         WRSN_PROF_CNT(14, j)
-                        continue;
-                    }
-                } else if (kk + 1.0 < t_limit && (!net_active || kk + 1.0 < max_time)) {
-                    // one whole second, straight-line: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge
-                    fused = true;
-                    if (any_rr) {
-#pragma unroll
-                        for (int j = 0; j < NPL; ++j) { const double e = fmin(E[j] - d1[j] + rrh[j], cap) - d2[j]; E[j] = ((am >> j) & 1u) ? e : E[j]; }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NPL; ++j) E[j] = (E[j] - d1[j]) - d2[j];
-                    }
-                    now = kk + 1.0;
-                    do_ur = ur_flag;
+                    } else { fused = true; nrep = j; do_ur = ur_flag; WRSN_PROF_CNT(13, j) }
+                    const double ke = kk + (double)j;
+                    ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
+                    if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
+                    else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; }
+                    now = ke; n_ticks += j; safe_ticks -= j;
+                    if (!fused) continue;
                 }
             }
             if (!fused) {
@@ -907,26 +896,32 @@ struct Sim {
                         else { net_phase = 0; net_time = now + 1.0 / 10.0; net_seq = seq++; }
                     }
                 } else if (k == 1) {
-                    do_ur = ur_flag;
+                    do_ur = ur_flag; nrep = do_ur ? 1 : 0;
                     ur_time = now + 1.0; ur_seq = seq++;
                 } else {
                     if (node_phase == 0) { node_half(rrh, any_rr); node_phase = 1; } else { node_full(rrh, any_rr); node_phase = 0; }
                     node_time = now + 1.0 * 0.5; node_seq = seq++;
                 }
             }
-            if (do_ur) update_reward();                      // the one call site
-            if (fused) {
-                if (any_rr) {
+            // ---- the steady loop: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge (Node.py:68),
+            //      repeated for every whole second taken above; a lone reward item of the generic path runs it once
+            for (int q = 0; q < nrep; ++q) {
+                if (fused) {
+                    if (any_rr) {
+#pragma unroll
+                        for (int j = 0; j < NPL; ++j) { const double e = fmin(E[j] - d1[j] + rrh[j], cap) - d2[j]; E[j] = ((am >> j) & 1u) ? e : E[j]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NPL; ++j) E[j] = (E[j] - d1[j]) - d2[j];
+                    }
+                }
+                if (do_ur) update_reward();                  // the one call site
+                if (fused && any_rr) {
 #pragma unroll
                     for (int j = 0; j < NPL; ++j) { const double e = fmin(E[j] + rrh[j], cap); E[j] = ((am >> j) & 1u) ? e : E[j]; }
                 }
-                ur_time = now + 1.0; node_time = now + 1.0 * 0.5;
-                if (net_active) { net_time = now + 1.0 / 10.0; seq += 5; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
-                else { seq += 3; ur_seq = seq - 2; node_seq = seq - 1; }
-                n_ticks++; safe_ticks--;
-                WRSN_PROF_CNT(13, 1)
-                continue;
             }
+            if (fused) continue;
             if (one || deaths_flag) break;
         }
         if (ur_flag) ur_flush();
@@ -1569,11 +1564,18 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     }
 }
 
-// ------------------------------------------------------------------ observation kernel: WRSN.get_state (WRSN.py:130-186)
-// 256 threads per environment.  map_1 is a rank-N sum of separable Gaussians: node chunks are expanded into
-// w*g(x) and g(y) rows in LDS and each thread accumulates a ROWS x 4 register tile; maps 2-4 are rank-1 terms.
-#define WRSN_OBS_CH 32
 #define WRSN_OBS_MAXROWS 16
+// ------------------------------------------------------------------ observation kernel: WRSN.get_state (WRSN.py:130-186)
+// map_1[i][j] = sum over alive nodes of w_n g(x_i - x_n; hX) g(y_j - y_n; hY) is a rank-N sum of separable Gaussians,
+// i.e. the GEMM (w .* Gx)^T Gy with M = N = G (100) and K = #nodes: it runs on the matrix cores with the exact-f32
+// v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain over the nodes).  One 256-thread workgroup per environment: wave w
+// owns the 32-row band w of the (padded 128 x 128) map = 4 accumulator tiles; node chunks are expanded into LDS rows
+// A[k][i] = w_k g(x_i - x_k), B[k][j] = g(y_j - y_k).  Maps 2-4 are at most M rank-1 terms and stay on the VALU.
+#define WRSN_OBS_CH 32
+#define WRSN_OBS_LD 128
+#ifndef WRSN_V16F_DEFINED
+typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
+#endif
 __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
     extern __shared__ double smem[];
     const int env = blockIdx.x, tid = threadIdx.x;
@@ -1583,23 +1585,20 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
     const int N = ec->n_node, NP = d.NP, G = d.G, M = d.M;
     const size_t nb = (size_t)env * NP;
     const WrsnEnvDyn* dy = d.live.dyn + env;
-    float* A = (float*)smem;                        // [CH][G]  weight * g(x - x_n)
-    float* Bm = A + WRSN_OBS_CH * G;                // [CH][G]  g(y - y_n)
-    double* pc = (double*)(Bm + WRSN_OBS_CH * G);   // [CH][3]  cx, cy, weight
+    float* A = (float*)smem;                               // [CH][LD]  weight * g(x - x_n), zero beyond G
+    float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n)
+    double* pc = (double*)(Bm + WRSN_OBS_CH * WRSN_OBS_LD);   // [CH][3]  cx, cy, weight
     const double W = ec->frame[1] - ec->frame[0], H = ec->frame[3] - ec->frame[2];
     const double unit = 1.0 / G;
-    const int CG = (G + 3) / 4;                     // column groups of 4
-    const int RG = 256 / CG;                        // row groups
-    const int RPG = (G + RG - 1) / RG;              // rows per group (<= WRSN_OBS_MAXROWS)
-    const int cg = tid % CG, rg = tid / CG;
-    const bool worker = rg < RG;
-    const int i0 = rg * RPG, j0 = cg * 4;
-    float acc[WRSN_OBS_MAXROWS][4];
-#pragma unroll
-    for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
     const double hX = ec->charging_range / W, hY = ec->charging_range / H;
     const float inv2hx = (float)(-1.0 / (2.0 * hX * hX)), inv2hy = (float)(-1.0 / (2.0 * hY * hY));
     float* out = obs + (size_t)env * 4 * G * G;
+    const int wave = tid >> 6, l = tid & 63, half = l >> 5, l31 = l & 31;
+    const int row0 = 32 * wave;                            // this wave's band of map rows
+    const bool band = row0 < G;
+    wrsn_v16f acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH) {
         __syncthreads();
@@ -1613,51 +1612,56 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
             pc[tid * 3 + 0] = cx; pc[tid * 3 + 1] = cy; pc[tid * 3 + 2] = w;
         }
         __syncthreads();
-        for (int idx = tid; idx < WRSN_OBS_CH * 2 * G; idx += 256) {
-            int n = idx / (2 * G), r = idx - n * 2 * G;
-            bool isx = r < G; int c = isx ? r : r - G;
-            double cen = unit / 2 + c * unit;
-            float df = (float)(cen - pc[n * 3 + (isx ? 0 : 1)]);
-            float g = __expf(df * df * (isx ? inv2hx : inv2hy));
-            if (isx) A[n * G + c] = g * (float)pc[n * 3 + 2]; else Bm[n * G + c] = g;
+        for (int idx = tid; idx < WRSN_OBS_CH * 2 * WRSN_OBS_LD; idx += 256) {
+            const int n = idx / (2 * WRSN_OBS_LD), r = idx - n * 2 * WRSN_OBS_LD;
+            const bool isx = r < WRSN_OBS_LD; const int c = isx ? r : r - WRSN_OBS_LD;
+            float v = 0.f;
+            if (c < G) {
+                const double cen = unit / 2 + c * unit;
+                const float df = (float)(cen - pc[n * 3 + (isx ? 0 : 1)]);      // difference in float64, then float32
+                v = __expf(df * df * (isx ? inv2hx : inv2hy));
+                if (isx) v *= (float)pc[n * 3 + 2];
+            }
+            if (isx) A[n * WRSN_OBS_LD + c] = v; else Bm[n * WRSN_OBS_LD + c] = v;
         }
         __syncthreads();
-        if (worker) {
-            for (int n = 0; n < WRSN_OBS_CH; ++n) {
-                float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                if (j0 < G) b0 = Bm[n * G + j0];
-                if (j0 + 1 < G) b1 = Bm[n * G + j0 + 1];
-                if (j0 + 2 < G) b2 = Bm[n * G + j0 + 2];
-                if (j0 + 3 < G) b3 = Bm[n * G + j0 + 3];
+        if (band) {
+#pragma unroll 4
+            for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
+                // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
+                const float a = A[(k2 + half) * WRSN_OBS_LD + row0 + l31];
 #pragma unroll
-                for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) {
-                    if (r < RPG && i0 + r < G) {
-                        float a = A[n * G + i0 + r];
-                        acc[r][0] += a * b0; acc[r][1] += a * b1; acc[r][2] += a * b2; acc[r][3] += a * b3;
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    const float b = Bm[(k2 + half) * WRSN_OBS_LD + 32 * t + l31];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
         }
     }
-    __syncthreads();
-    // rank-1 terms of maps 2..4: rows gx/gy per term in LDS
-    // term list: own charger (map 2), others charging (map 3), others moving (map 4)
-    float* gx = A; float* gy = A + G;
-    const WrsnAgent* ag = dy->ag;
-    // map 1 store
-    if (worker) {
+    // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (band) {
 #pragma unroll
-        for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) {
-            if (r < RPG && i0 + r < G) {
-                float* o = out + (size_t)(i0 + r) * G + j0;
-                for (int c = 0; c < 4; ++c) if (j0 + c < G) o[c] = acc[r][c];
+        for (int t = 0; t < 4; ++t) {
+            const int j = 32 * t + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (i < G && j < G) out[(size_t)i * G + j] = acc[t][r];
             }
         }
     }
-    // maps 2..4
+    __syncthreads();
+    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4); thread = (row group, 4 columns)
+    float* gx = A; float* gy = A + WRSN_OBS_LD;
+    const WrsnAgent* ag = dy->ag;
+    const int CG = (G + 3) / 4, RG = 256 / CG, RPG = (G + RG - 1) / RG;
+    const int cg = tid % CG, rg = tid / CG;
+    const bool worker = rg < RG;
+    const int i0 = rg * RPG, j0 = cg * 4;
     for (int mp = 1; mp < 4; ++mp) {
+        float a2[WRSN_OBS_MAXROWS][4];
 #pragma unroll
-        for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+        for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) { a2[r][0] = a2[r][1] = a2[r][2] = a2[r][3] = 0.f; }
         for (int o = 0; o < M; ++o) {
             double cxo, cyo, hx, hy, val;
             if (mp == 1) {
@@ -1689,7 +1693,7 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
                 for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) {
                     if (r < RPG && i0 + r < G) {
                         float a = gx[i0 + r];
-                        for (int c = 0; c < 4; ++c) if (j0 + c < G) acc[r][c] += a * gy[j0 + c];
+                        for (int c = 0; c < 4; ++c) if (j0 + c < G) a2[r][c] += a * gy[j0 + c];
                     }
                 }
             }
@@ -1699,11 +1703,11 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
             for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) {
                 if (r < RPG && i0 + r < G) {
                     float* o = out + (size_t)mp * G * G + (size_t)(i0 + r) * G + j0;
-                    for (int c = 0; c < 4; ++c) if (j0 + c < G) o[c] = acc[r][c];
+                    for (int c = 0; c < 4; ++c) if (j0 + c < G) o[c] = a2[r][c];
                 }
             }
         }
     }
 }
 
-static inline int wrsn_obs_lds_bytes(int G) { return WRSN_OBS_CH * G * 4 * 2 + WRSN_OBS_CH * 3 * 8 + 64; }
+static inline int wrsn_obs_lds_bytes(int G) { (void)G; return WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + WRSN_OBS_CH * 3 * 8 + 64; }

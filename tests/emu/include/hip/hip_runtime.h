@@ -106,6 +106,27 @@ inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float emu_exp2f(float x) { return exp2f(x); }
 #define __builtin_amdgcn_exp2f emu_exp2f
 
+// ---- v_mfma_f32_32x32x2_f32: A lane l -> A[i = l & 31][k = l >> 5], B lane l -> B[k = l >> 5][j = l & 31],
+//      D[reg][lane]: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)   (one k-ordered fmaf chain)
+struct wrsn_v16f { float v[16]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+#define WRSN_V16F_DEFINED
+extern float emu_mfma_a[4][64], emu_mfma_b[4][64];
+inline wrsn_v16f emu_mfma_32x32x2(float a, float b, wrsn_v16f c, int, int, int) {
+    const int t = (int)threadIdx.x, w = t >> 6, l = t & 63;
+    emu_mfma_a[w][l] = a; emu_mfma_b[w][l] = b;
+    emu_barrier();
+    wrsn_v16f d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(emu_mfma_a[w][k * 32 + i], emu_mfma_b[w][k * 32 + j], acc);
+        d[r] = acc;
+    }
+    emu_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
+
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
