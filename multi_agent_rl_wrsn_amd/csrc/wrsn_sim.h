@@ -168,7 +168,7 @@ struct Sim {
     // node registers (per lane)
     double E[NPL], CS[NPL], d1[NPL], d2[NPL];
     unsigned am;                       // bit j: node j*64+lane alive
-    double cap, thr, max_time;
+    double cap, thr, max_time, inv_a_b2;   // inv_a_b2 = beta^2 / alpha (1 / the maximal charging rate, WRSN.py:125)
     // wave-uniform registers: identical in every lane.  `now` / `seq` are also advanced by lane 0 while it fires
     // charger events; they are re-broadcast through the mailbox at every hand-off.
     double opmax;
@@ -181,13 +181,13 @@ struct Sim {
     WRSN_PROF_DECL
 
     // lane-0 bookkeeping of the scalar event processor lives in LDS, not in registers
-    struct Scalar { double ev_time; int64_t ev_seq, n_events; int32_t L, pend, pend_idx, ev_valid, ev_kind, ev_idx, ev_prio, ev_uf; };
+    struct Scalar { double ev_time, ev2_time; int64_t ev_seq, n_events; int32_t L, pend, pend_idx, ev_valid, ev_kind, ev_idx, ev_prio, ev_uf; };
     static_assert(sizeof(Scalar) == WRSN_LDS_SCALAR_BYTES, "wrsn_lds_bytes must match");
 
     // ---- static topology / per-environment arrays in HBM
     // per-environment constants are staged in LDS by bind(): a plain global load of them costs a full memory round
     // trip (the backend cannot use scalar loads on mutable global memory)
-    WDEV const WrsnEnvConst* EC() const { return (const WrsnEnvConst*)(((uintptr_t)(SURAGENT() + M * WRSN_CONN_CAP) + 7) & ~(uintptr_t)7); }
+    WDEV const WrsnEnvConst* EC() const { return (const WrsnEnvConst*)(SS() + 1); }
     WDEV const double* NX() const { return dp->node_x + (size_t)env * NP; }
     WDEV const double* NY() const { return dp->node_y + (size_t)env * NP; }
     WDEV const double* DBS() const { return dp->dist_bs + (size_t)env * NP; }
@@ -214,7 +214,7 @@ struct Sim {
     WDEV double* SURACC() const { return SURRATE() + M * WRSN_CONN_CAP; }
     WDEV double* SREQD() const { return SURACC() + M * WRSN_CONN_CAP; }                 // [0] time limit, [1] now, [2] seq (as int64), [3] spare
     WDEV Scalar* SS() const { return (Scalar*)(SREQD() + 4); }
-    WDEV int32_t* SREQ() const { return (int32_t*)(SS() + 1); }                           // [0] request, [1] argument, [2] live connections, [3] flags
+    WDEV int32_t* SREQ() const { return (int32_t*)(EC() + 1); }                           // [0] request, [1] argument, [2] live connections, [3] flags
     WDEV int32_t* SCA() const { return SREQ() + 4; }
     WDEV int32_t* SCTR() const { return SCA() + (M + 1); }
     WDEV int32_t* SCP() const { return SCTR() + (M + 1); }
@@ -234,6 +234,7 @@ struct Sim {
         __syncthreads();
         N = EC()->n_node; T = EC()->n_target;
         cap = EC()->capacity; thr = EC()->threshold; max_time = EC()->max_time;
+        inv_a_b2 = (EC()->beta * EC()->beta) / EC()->alpha;
         err = 0; deaths_flag = 0;
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
@@ -698,7 +699,7 @@ struct Sim {
         const float mean = s1 * invn;
         float var = fmaf(-mean, mean, s2 * invn);
         var = var > 0.f ? var : 0.f;
-        float sd = __builtin_sqrtf(var);
+        float sd = __builtin_amdgcn_sqrtf(var);
         if (sd == 0.f) sd = epsf;
         const float k2 = 1.44269504f * __builtin_amdgcn_rcpf(sd);     // exp(z) = 2^(z * log2 e)
         float ex[NPL]; float es = 0.f;
@@ -706,7 +707,7 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) { const float v = (j * 64 + lane < N) ? __builtin_amdgcn_exp2f((x[j] - mean) * k2) : 0.f; ex[j] = v; es += v; }
         float tot = wv_sumf(es);
         if (tot == 0.f) tot = epsf;
-        const double scale = 1.0 / ((double)tot * (EC()->alpha / (EC()->beta * EC()->beta)));
+        const double scale = (double)__builtin_amdgcn_rcpf(tot) * inv_a_b2;
         const int n = SURN()[0];
         for (int k = 0; k < n; ++k) {
             const int i = SURIDX()[k];
@@ -766,21 +767,23 @@ struct Sim {
             t[i] = tc[j];
         }
         __syncthreads();
+        // labels only grow towards the unique fixed point, so the relaxation may read labels other lanes are updating
+        // in the same sweep: fewer sweeps than Jacobi, one barrier per sweep
+        unsigned nd = 0;                                     // non-direct alive slots of this lane
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) if (((am >> j) & 1u) && !(NFLAGS()[j * 64 + lane] & 1)) nd |= 1u << j;
         for (int it = 0; it <= N; ++it) {
             bool ch = false;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 int i = j * 64 + lane;
-                if (((am >> j) & 1u) && !(NFLAGS()[i] & 1)) {
+                if ((nd >> j) & 1u) {
                     double best = -1.0;
                     WRSN_FOR_NEIGHBORS(nbr, j, i, nb, { best = fmax(best, t[nb]); })      // dead / unreached neighbours hold -1
                     double cand = fmin(lt[j], best);
-                    if (cand > tc[j]) { tc[j] = cand; ch = true; }
+                    if (cand > tc[j]) { tc[j] = cand; t[i] = cand; ch = true; }
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) t[j * 64 + lane] = tc[j];
             __syncthreads();
             if (!wv_any(ch)) break;
         }
@@ -1240,15 +1243,17 @@ struct Sim {
         SS()->pend = 0;
         for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
             if (!SS()->ev_valid) {                                 // charger / condition state only changes when one of them fires
-                int kind_ = -1, idx_ = 0; double bt_ = 0.0; int bp_ = 0; int64_t bs_ = 0;
-#define WRSN_CONSIDER(K, I, T_, P_, S_) if (kind_ < 0 || key_less((T_), (P_), (S_), bt_, bp_, bs_)) { kind_ = (K); idx_ = (I); bt_ = (T_); bp_ = (P_); bs_ = (S_); }
+                int kind_ = -1, idx_ = 0; double bt_ = 0.0; int bp_ = 0; int64_t bs_ = 0; double t2_ = WRSN_INF;
+#define WRSN_CONSIDER(K, I, T_, P_, S_) { const double tt_ = (T_); \
+                    if (kind_ < 0 || key_less(tt_, (P_), (S_), bt_, bp_, bs_)) { if (kind_ >= 0 && bt_ < t2_) t2_ = bt_; kind_ = (K); idx_ = (I); bt_ = tt_; bp_ = (P_); bs_ = (S_); } \
+                    else if (tt_ < t2_) t2_ = tt_; }
                 for (int i = 0; i < 2 * M; ++i) {
                     int pc = STH()[i].pc;
-                    if (pc != PC_NONE && pc != PC_FINISHED) { WRSN_CONSIDER(3, i, STH()[i].time, STH()[i].prio, STH()[i].seq) }
+                    if (pc != PC_NONE && pc != PC_FINISHED) WRSN_CONSIDER(3, i, STH()[i].time, STH()[i].prio, STH()[i].seq)
                 }
-                for (int j = 1; j <= SS()->L; ++j) if (SCP()[j]) { WRSN_CONSIDER(4, j, SCT()[j], WRSN_NORMAL, SCS()[j]) }
+                for (int j = 1; j <= SS()->L; ++j) if (SCP()[j]) WRSN_CONSIDER(4, j, SCT()[j], WRSN_NORMAL, SCS()[j])
 #undef WRSN_CONSIDER
-                SS()->ev_kind = kind_; SS()->ev_idx = idx_; SS()->ev_time = bt_; SS()->ev_prio = bp_; SS()->ev_seq = bs_; SS()->ev_uf = ur_flags(); if (SS()->ev_uf & 1) ur_build(); else SURN()[0] = 0; SS()->ev_valid = 1;
+                SS()->ev_kind = kind_; SS()->ev_idx = idx_; SS()->ev_time = bt_; SS()->ev_prio = bp_; SS()->ev_seq = bs_; SS()->ev2_time = t2_; SS()->ev_valid = 1; SS()->ev_uf = -1;
             }
             const int kind = SS()->ev_kind, idx = SS()->ev_idx, bp = SS()->ev_prio; const double bt = SS()->ev_time; const int64_t bs = SS()->ev_seq;
             const bool have_ev = kind >= 0;
@@ -1262,6 +1267,11 @@ struct Sim {
             if (!have_ev && !have_grid) { err = -7; return REQ_STOP; }      // cannot happen while a charger process runs
             double t_lim = have_ev ? bt : WRSN_INF;
             if (use_limit && limit < t_lim) t_lim = limit;
+            if (have_grid && (gt < t_lim || (have_ev && gt == bt)) && SS()->ev_uf < 0) {
+                // the reward entry list is only needed by a grid service: (re)build it lazily
+                SS()->ev_uf = ur_flags();
+                if (SS()->ev_uf & 1) ur_build(); else SURN()[0] = 0;
+            }
             if (have_grid && gt < t_lim) {
                 const int uf = SS()->ev_uf;
                 if (uf & 2) { ff_sync_all(gt); ur_build(); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
@@ -1280,6 +1290,16 @@ struct Sim {
             if (kind == 3) {
                 int r = thread_fire(idx);
                 if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; return r; }
+                // the same process usually owns the next event too (its hops at one instant, or its next timeout is
+                // the earliest): no rescan when nothing else can come first
+                const int pc2 = STH()[idx].pc;
+                if (pc2 != PC_NONE && pc2 != PC_FINISHED) {
+                    const double t2 = STH()[idx].time;
+                    if (t2 < SS()->ev2_time && (!have_grid || t2 < gt)) {
+                        SS()->ev_kind = 3; SS()->ev_idx = idx; SS()->ev_time = t2; SS()->ev_prio = STH()[idx].prio; SS()->ev_seq = STH()[idx].seq;
+                        SS()->ev_valid = 1; SS()->ev_uf = -1;
+                    }
+                }
             } else {
                 SCP()[idx] = 0;
                 if (idx == SS()->L) return REQ_STOP;               // StopSimulation
@@ -1324,11 +1344,12 @@ struct Sim {
 // wrsn_step_kernel  : WRSN.step (WRSN.py:289-330); with `reset_call` (or auto-reset of a terminal environment) it
 //                     restores the snapshot into d.live and emits the reset request instead        (WRSN.py:66-75)
 // Two kernels so that the event machine and every O(N) routine are instantiated once per code object.
+// two waves per SIMD (256 registers) for up to 256 nodes: the event machine is latency-bound, a second wave hides it
 #ifndef WRSN_WAVES_PER_SIMD
-#define WRSN_WAVES_PER_SIMD 1
+#define WRSN_WAVES_PER_SIMD(NPL_) ((NPL_) <= 4 ? 2 : 1)
 #endif
 template <int NPL>
-__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD) wrsn_warmup_kernel(const WrsnDev* __restrict__ dp, int env0) {
+__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kernel(const WrsnDev* __restrict__ dp, int env0) {
     extern __shared__ double smem[];
     const int env = env0 + blockIdx.x;
     const int lane = threadIdx.x;
@@ -1391,7 +1412,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD) wrsn_warmup_kernel(co
 }
 
 template <int NPL>
-__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
+__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
                                                        const double* __restrict__ action, int auto_reset,
                                                        const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
     extern __shared__ double smem[];

@@ -89,7 +89,7 @@ struct WrsnStepOutDev {
     int32_t *agent_id; double *reward; uint8_t *terminal; double *now; float *obs; int32_t *status;
 };
 
-#define WRSN_LDS_SCALAR_BYTES 56
+#define WRSN_LDS_SCALAR_BYTES 64
 // LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h)
 static inline int wrsn_lds_bytes(int NP, int M) {
     int b = 0;

@@ -103,6 +103,8 @@ inline float emu_rcpf(float x) { return 1.0f / x; }
 #define __builtin_amdgcn_rcpf emu_rcpf
 inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline float emu_sqrtf(float x) { return sqrtf(x); }
+#define __builtin_amdgcn_sqrtf emu_sqrtf
 inline float emu_exp2f(float x) { return exp2f(x); }
 #define __builtin_amdgcn_exp2f emu_exp2f
 
