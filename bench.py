@@ -148,15 +148,23 @@ def main():
         t_env += ev[0].elapsed_time(ev[1]) * 1e-3
         t_obs += ev[1].elapsed_time(ev[2]) * 1e-3
     steps_k = env.counters()["env_steps"] - steps_before
+    info_ticks = env.env_info()["n_ticks"]                      # simulated seconds of the running episodes
     phys_b, obs_b = algorithmic_bytes(N, T, M, G)
     env_launch = t_env / ks; obs_launch = t_obs / ks
     units = steps_k / ks                                        # env-steps one launch processes (auto-resets excluded)
     if env_launch >= obs_launch:
-        dom, dur, per_unit = "wrsn_env_kernel", env_launch, phys_b
+        dom, dur, per_unit = "wrsn_step_kernel", env_launch, phys_b
     else:
         dom, dur, per_unit = "wrsn_obs_kernel", obs_launch, obs_b
     achieved = per_unit * units / dur / 1e9
     peak = 8000.0
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or null
+    traffic = None
+    try:
+        tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))[-1]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"][dom]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
 
     if rank == 0:
         value = env_steps / elapsed
@@ -167,11 +175,11 @@ def main():
             "vs_baseline": None, "dtype": "f64 (physics) / f32 (observation)", "data": "synthetic",
             "config": {"workload": "%d envs/GPU x %d nodes x %d targets x %d MC, random policy U[0,1)^3, auto-reset, 4x%dx%d observation" % (B, N, T, M, G, G),
                        "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "parallelism": "env-shard x%d" % world},
-            "env_steps_timed": env_steps, "sim_ticks_per_s": None, "mean_return_table_rows": int(table.shape[0]),
+            "env_steps_timed": env_steps, "mean_episode_seconds_so_far": float(info_ticks.mean()), "mean_return_table_rows": int(table.shape[0]),
             "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(t_set, 2)},
-            "kernels": {"wrsn_env_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},
+            "kernels": {"wrsn_step_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": None, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": per_unit * units, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
                          "whole_step_achieved_GBps": (phys_b + obs_b) * value / 1e9, "whole_step_frac": (phys_b + obs_b) * value / 1e9 / peak},
         }
         if args.cpu_seconds > 0 and world == 1:
