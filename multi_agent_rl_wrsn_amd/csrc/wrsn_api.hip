@@ -162,7 +162,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         int RPG = (d.G + RG - 1) / RG; if (RPG > WRSN_OBS_MAXROWS) { delete h; return fail(WRSN_ERR_ARG, "map_size too large for the observation tile"); }
     }
     h->lds_env = wrsn_lds_bytes(d.NP, d.M);
-    h->lds_obs = wrsn_obs_lds_bytes(d.G);
+    h->lds_obs = wrsn_obs_lds_bytes(d.G, d.NP);
     const size_t B = d.B, NP = d.NP;
     int rc = 0;
     do {

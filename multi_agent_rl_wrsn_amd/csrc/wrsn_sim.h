@@ -1606,10 +1606,11 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
     const int N = ec->n_node, NP = d.NP, G = d.G, M = d.M;
     const size_t nb = (size_t)env * NP;
     const WrsnEnvDyn* dy = d.live.dyn + env;
-    float* A = (float*)smem;                               // [CH][LD]  weight * g(x - x_n), zero beyond G
+    double* pc = smem;                                     // [NP][3]  cx, cy, weight of every node (0 weight: dead)
+    float* A = (float*)(pc + 3 * NP);                      // [CH][LD]  weight * g(x - x_n), zero beyond G
     float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n)
-    double* pc = (double*)(Bm + WRSN_OBS_CH * WRSN_OBS_LD);   // [CH][3]  cx, cy, weight
-    const double W = ec->frame[1] - ec->frame[0], H = ec->frame[3] - ec->frame[2];
+    const double fx0 = ec->frame[0], fy0 = ec->frame[2];
+    const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
     const double unit = 1.0 / G;
     const double hX = ec->charging_range / W, hY = ec->charging_range / H;
     const float inv2hx = (float)(-1.0 / (2.0 * hX * hX)), inv2hy = (float)(-1.0 / (2.0 * hY * hY));
@@ -1617,31 +1618,32 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
     const int wave = tid >> 6, l = tid & 63, half = l >> 5, l31 = l & 31;
     const int row0 = 32 * wave;                            // this wave's band of map rows
     const bool band = row0 < G;
+    {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
+        const double a_b2 = ec->alpha / (ec->beta * ec->beta), thr = ec->threshold, span = ec->capacity - ec->threshold;
+        for (int n = tid; n < NP; n += 256) {
+            double w = 0.0, cx = 0.0, cy = 0.0;
+            if (n < N && (d.live.ls[nb + n] & 1)) {
+                cx = (d.node_x[nb + n] - fx0) / W; cy = (d.node_y[nb + n] - fy0) / H;
+                w = (d.live.CS[nb + n] / a_b2) / ((d.live.E[nb + n] - thr) / span);
+            }
+            pc[n * 3 + 0] = cx; pc[n * 3 + 1] = cy; pc[n * 3 + 2] = w;
+        }
+    }
     wrsn_v16f acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH) {
-        __syncthreads();
-        if (tid < WRSN_OBS_CH) {
-            int n = c0 + tid; double w = 0.0, cx = 0.0, cy = 0.0;
-            if (n < N && (d.live.ls[nb + n] & 1)) {
-                cx = (d.node_x[nb + n] - ec->frame[0]) / W; cy = (d.node_y[nb + n] - ec->frame[2]) / H;
-                double e = d.live.E[nb + n], cs = d.live.CS[nb + n];
-                w = (cs / (ec->alpha / (ec->beta * ec->beta))) / ((e - ec->threshold) / (ec->capacity - ec->threshold));
-            }
-            pc[tid * 3 + 0] = cx; pc[tid * 3 + 1] = cy; pc[tid * 3 + 2] = w;
-        }
-        __syncthreads();
+        __syncthreads();                                   // pc ready / previous chunk consumed
         for (int idx = tid; idx < WRSN_OBS_CH * 2 * WRSN_OBS_LD; idx += 256) {
-            const int n = idx / (2 * WRSN_OBS_LD), r = idx - n * 2 * WRSN_OBS_LD;
-            const bool isx = r < WRSN_OBS_LD; const int c = isx ? r : r - WRSN_OBS_LD;
+            const int n = idx >> 8, r = idx & 255;         // LD = 128: 256 entries (x row, y row) per node
+            const bool isx = r < WRSN_OBS_LD; const int c = r & (WRSN_OBS_LD - 1);
             float v = 0.f;
-            if (c < G) {
+            if (c < G && c0 + n < N) {
                 const double cen = unit / 2 + c * unit;
-                const float df = (float)(cen - pc[n * 3 + (isx ? 0 : 1)]);      // difference in float64, then float32
+                const float df = (float)(cen - pc[(c0 + n) * 3 + (isx ? 0 : 1)]);      // difference in float64, then float32
                 v = __expf(df * df * (isx ? inv2hx : inv2hy));
-                if (isx) v *= (float)pc[n * 3 + 2];
+                if (isx) v *= (float)pc[(c0 + n) * 3 + 2];
             }
             if (isx) A[n * WRSN_OBS_LD + c] = v; else Bm[n * WRSN_OBS_LD + c] = v;
         }
@@ -1672,63 +1674,43 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
         }
     }
     __syncthreads();
-    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4); thread = (row group, 4 columns)
-    float* gx = A; float* gy = A + WRSN_OBS_LD;
+    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.
+    // Term rows gx[t][G] (already scaled) and gy[t][G] go to LDS; every thread then produces elements tid, tid+256, ...
+    float* tx = A; float* ty = A + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
     const WrsnAgent* ag = dy->ag;
-    const int CG = (G + 3) / 4, RG = 256 / CG, RPG = (G + RG - 1) / RG;
-    const int cg = tid % CG, rg = tid / CG;
-    const bool worker = rg < RG;
-    const int i0 = rg * RPG, j0 = cg * 4;
-    for (int mp = 1; mp < 4; ++mp) {
-        float a2[WRSN_OBS_MAXROWS][4];
-#pragma unroll
-        for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) { a2[r][0] = a2[r][1] = a2[r][2] = a2[r][3] = 0.f; }
+    for (int o = 0; o < M; ++o) {
+        int mp; double cxo, cyo, hx, hy, val;
+        if (o == aid) {
+            mp = 1;
+            cxo = (ag[o].loc[0] - fx0) / W; cyo = (ag[o].loc[1] - fy0) / H;
+            const double tmp = H < W ? H : W;
+            hx = 0.5 * tmp / W; hy = 0.5 * tmp / H;
+            val = ag[o].energy / ec->mc_capacity;
+        } else {
+            cxo = (ag[o].cur[0] - fx0) / W; cyo = (ag[o].cur[1] - fy0) / H; hx = hX; hy = hY;
+            if (ag[o].type_charging) { mp = 2; val = ag[o].cur[2] / ec->charging_time_max; }          // map_3: others not "moving"
+            else { mp = 3; val = (dist2(ag[o].loc[0], ag[o].loc[1], ag[o].cur[0], ag[aid].cur[1]) / ec->velocity) / ec->moving_time_max; }   // map_4, mixed index as in WRSN.py:184
+        }
+        for (int idx = tid; idx < 2 * G; idx += 256) {
+            const bool isx = idx < G; const int c = isx ? idx : idx - G;
+            const double cen = unit / 2 + c * unit;
+            const double df = cen - (isx ? cxo : cyo); const double h = isx ? hx : hy;
+            const float g = __expf((float)(df * df / (-2.0 * h * h)));
+            if (isx) tx[o * WRSN_OBS_LD + c] = g * (float)val; else ty[o * WRSN_OBS_LD + c] = g;
+        }
+        if (tid == 0) tmap[o] = mp;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * G; idx += 256) {
+        const int i = idx / G, j = idx - i * G;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f;
         for (int o = 0; o < M; ++o) {
-            double cxo, cyo, hx, hy, val;
-            if (mp == 1) {
-                if (o != aid) continue;
-                cxo = (ag[o].loc[0] - ec->frame[0]) / W; cyo = (ag[o].loc[1] - ec->frame[2]) / H;
-                double tmp = H < W ? H : W;
-                hx = 0.5 * tmp / W; hy = 0.5 * tmp / H;
-                val = ag[o].energy / ec->mc_capacity;
-            } else {
-                if (o == aid) continue;
-                if (mp == 2 && !ag[o].type_charging) continue;      // map_3: others not "moving"
-                if (mp == 3 && ag[o].type_charging) continue;       // map_4: others not "charging"
-                cxo = (ag[o].cur[0] - ec->frame[0]) / W; cyo = (ag[o].cur[1] - ec->frame[2]) / H;
-                hx = hX; hy = hY;
-                if (mp == 2) val = ag[o].cur[2] / ec->charging_time_max;
-                else val = (dist2(ag[o].loc[0], ag[o].loc[1], ag[o].cur[0], ag[aid].cur[1]) / ec->velocity) / ec->moving_time_max;   // mixed index as in WRSN.py:184
-            }
-            __syncthreads();
-            for (int idx = tid; idx < 2 * G; idx += 256) {
-                bool isx = idx < G; int c = isx ? idx : idx - G;
-                double cen = unit / 2 + c * unit;
-                double df = cen - (isx ? cxo : cyo); double h = isx ? hx : hy;
-                float g = __expf((float)(df * df / (-2.0 * h * h)));
-                if (isx) gx[c] = g * (float)val; else gy[c] = g;
-            }
-            __syncthreads();
-            if (worker) {
-#pragma unroll
-                for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) {
-                    if (r < RPG && i0 + r < G) {
-                        float a = gx[i0 + r];
-                        for (int c = 0; c < 4; ++c) if (j0 + c < G) a2[r][c] += a * gy[j0 + c];
-                    }
-                }
-            }
+            const float p = tx[o * WRSN_OBS_LD + i] * ty[o * WRSN_OBS_LD + j];
+            const int mp = tmap[o];
+            v1 += (mp == 1) ? p : 0.f; v2 += (mp == 2) ? p : 0.f; v3 += (mp == 3) ? p : 0.f;
         }
-        if (worker) {
-#pragma unroll
-            for (int r = 0; r < WRSN_OBS_MAXROWS; ++r) {
-                if (r < RPG && i0 + r < G) {
-                    float* o = out + (size_t)mp * G * G + (size_t)(i0 + r) * G + j0;
-                    for (int c = 0; c < 4; ++c) if (j0 + c < G) o[c] = a2[r][c];
-                }
-            }
-        }
+        out[(size_t)G * G + idx] = v1; out[(size_t)2 * G * G + idx] = v2; out[(size_t)3 * G * G + idx] = v3;
     }
 }
 
-static inline int wrsn_obs_lds_bytes(int G) { (void)G; return WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + WRSN_OBS_CH * 3 * 8 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return NP * 3 * 8 + WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }
