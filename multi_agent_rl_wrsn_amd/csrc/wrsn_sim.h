@@ -20,6 +20,7 @@
 #include "wrsn_types.h"
 
 #define WDEV __device__ __forceinline__
+#define WRSN_CHG_MAX 8                    // nodes under charge handled by the time-parallel steady batch
 // Diagnostic build only (-DWRSN_PROFILE, tools/build_profile.sh): per-phase cycle totals per environment.  Stamps go
 // to a buffer of their own (WrsnDev.counters) and no output is computed from them; the product build has none.
 #ifdef WRSN_PROFILE
@@ -205,7 +206,11 @@ struct Sim {
     WDEV double* SU() const { return smem_ + NP; }
     WDEV int32_t* SLS() const { return (int32_t*)(smem_ + 3 * NP); }
     WDEV int32_t* SRCV() const { return SLS() + NP; }
-    WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(smem_ + 4 * NP); }
+    // time-parallel steady batch: float CS per node, records / per-second table of the (few) nodes being charged
+    WDEV float* SCSF() const { return (float*)(smem_ + 4 * NP); }
+    WDEV double* SCHGREC() const { return smem_ + 4 * NP + NP / 2; }                       // [CHG_MAX][8]: E, d1, d2, rr, node, E_final, CS
+    WDEV double* SCHGTAB() const { return SCHGREC() + 8 * WRSN_CHG_MAX; }                 // [CHG_MAX][64] energy at the reward instant of second s
+    WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(SCHGTAB() + 64 * WRSN_CHG_MAX); }
     WDEV WrsnThread* STH() const { return (WrsnThread*)(SAG() + M); }
     WDEV double* SCT() const { return (double*)(STH() + 2 * M); }
     WDEV int64_t* SCS() const { return (int64_t*)(SCT() + (M + 1)); }
@@ -727,6 +732,140 @@ struct Sim {
         WRSN_PROF_ADD(3)
     }
 
+    // -------------------------------------------------------------- time-parallel steady batch
+    // nb (<= 64) consecutive whole seconds of the steady path at once: lane s owns second s and loops over the nodes,
+    // whose state is broadcast from LDS (one 16-byte and one 4-byte read per node, four nodes in flight).  Uncharged
+    // nodes follow E0 - (s+1)(d1+d2); the few nodes under charge get their clamped recursion (Node.py:60,68) tabulated
+    // per second by one lane each and are added after the main loops (they are staged as "priority 0" nodes, whose
+    // term is taken out again).  The reward priorities of every second (update_reward, WRSN.py:100-127) need no
+    // cross-lane reduction this way; the contributions of the connected nodes are summed over the seconds with one
+    // wave reduction per charger.  Returns false (nothing done) when more than WRSN_CHG_MAX nodes are being charged.
+    struct alignas(16) D2 { double x, y; };
+    struct alignas(8) F2 { float x, y; };
+    WDEV bool steady_batch(int nb, const double (&rrh)[NPL], bool any_rr) {
+        D2* sA = (D2*)SU(); float* sC = SCSF();
+        double* rec = SCHGREC(); double* tab = SCHGTAB();
+        const float epsf = 1e-9f;
+        // -- which nodes are being charged (half-rate != 0, alive)
+        int nchg = 0; unsigned cm = 0; int cpos[NPL];
+        if (any_rr) {
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const bool c = ((am >> j) & 1u) && rrh[j] != 0.0;
+                const unsigned long long mk = __ballot(c);
+                cpos[j] = nchg + __popcll(mk & ((1ull << lane) - 1ull));
+                if (c) {
+                    cm |= 1u << j;
+                    if (cpos[j] < WRSN_CHG_MAX) { double* r = rec + 8 * cpos[j]; r[0] = E[j]; r[1] = d1[j]; r[2] = d2[j]; r[3] = rrh[j]; r[4] = (double)(j * 64 + lane); r[6] = CS[j]; }
+                }
+                nchg += __popcll(mk);
+            }
+            if (nchg > WRSN_CHG_MAX) return false;
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = j * 64 + lane;
+            const bool lin = ((am >> j) & 1u) && !((cm >> j) & 1u);
+            D2 v; v.x = lin ? (E[j] - thr) : 1.0; v.y = lin ? (d1[j] + d2[j]) : 0.0;
+            sA[i] = v; sC[i] = lin ? (float)CS[j] : 0.f;
+        }
+        __syncthreads();
+        if (lane < nchg) {                                   // clamped recursion of one charged node over the nb seconds
+            double* r = rec + 8 * lane;
+            double e = r[0]; const double a1 = r[1], a2 = r[2], rr = r[3];
+            for (int q = 0; q < nb; ++q) { e = fmin(e - a1 + rr, cap) - a2; tab[lane * 64 + q] = e; e = fmin(e + rr, cap); }
+            r[5] = e;
+        }
+        __syncthreads();
+        const bool on = lane < nb;
+        const int ls = on ? lane : 0;
+        const double sp1 = -(double)(ls + 1);
+        const int N4 = N & ~3;
+        // -- pass 1: mean / variance of the priorities of "my" second
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        for (int i = 0; i < N4; i += 4) {
+            const D2 p0 = sA[i], p1 = sA[i + 1], p2 = sA[i + 2], p3 = sA[i + 3];
+            const F2 c01 = *(const F2*)(sC + i), c23 = *(const F2*)(sC + i + 2);
+            const double x0 = (double)(c01.x * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf));
+            const double x1 = (double)(c01.y * __builtin_amdgcn_rcpf((float)fma(sp1, p1.y, p1.x) + epsf));
+            const double x2 = (double)(c23.x * __builtin_amdgcn_rcpf((float)fma(sp1, p2.y, p2.x) + epsf));
+            const double x3 = (double)(c23.y * __builtin_amdgcn_rcpf((float)fma(sp1, p3.y, p3.x) + epsf));
+            a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+            b0 = fma(x0, x0, b0); b1 = fma(x1, x1, b1); b2 = fma(x2, x2, b2); b3 = fma(x3, x3, b3);
+        }
+        for (int i = N4; i < N; ++i) {
+            const D2 p0 = sA[i];
+            const double x0 = (double)(sC[i] * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf));
+            a0 += x0; b0 = fma(x0, x0, b0);
+        }
+        for (int c = 0; c < nchg; ++c) {
+            const double x0 = (double)((float)rec[8 * c + 6] * __builtin_amdgcn_rcpf((float)(tab[c * 64 + ls] - thr) + epsf));
+            a1 += x0; b1 = fma(x0, x0, b1);
+        }
+        const double s1 = (a0 + a1) + (a2 + a3), s2 = (b0 + b1) + (b2 + b3);
+        const double mean = s1 / N;
+        double var = s2 / N - mean * mean; var = var > 0.0 ? var : 0.0;
+        float sd = __builtin_amdgcn_sqrtf((float)var); if (sd == 0.f) sd = epsf;
+        const float k2 = 1.44269504f * __builtin_amdgcn_rcpf(sd);     // exp(z) = 2^(z * log2 e)
+        const float mk2 = -(float)mean * k2;
+        // -- pass 2: normaliser
+        a0 = 0.0; a1 = 0.0; a2 = 0.0; a3 = 0.0;
+        for (int i = 0; i < N4; i += 4) {
+            const D2 p0 = sA[i], p1 = sA[i + 1], p2 = sA[i + 2], p3 = sA[i + 3];
+            const F2 c01 = *(const F2*)(sC + i), c23 = *(const F2*)(sC + i + 2);
+            const float x0 = c01.x * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf);
+            const float x1 = c01.y * __builtin_amdgcn_rcpf((float)fma(sp1, p1.y, p1.x) + epsf);
+            const float x2 = c23.x * __builtin_amdgcn_rcpf((float)fma(sp1, p2.y, p2.x) + epsf);
+            const float x3 = c23.y * __builtin_amdgcn_rcpf((float)fma(sp1, p3.y, p3.x) + epsf);
+            a0 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2)); a1 += (double)__builtin_amdgcn_exp2f(fmaf(x1, k2, mk2));
+            a2 += (double)__builtin_amdgcn_exp2f(fmaf(x2, k2, mk2)); a3 += (double)__builtin_amdgcn_exp2f(fmaf(x3, k2, mk2));
+        }
+        for (int i = N4; i < N; ++i) {
+            const D2 p0 = sA[i];
+            const float x0 = sC[i] * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf);
+            a0 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2));
+        }
+        const double ez = (double)__builtin_amdgcn_exp2f(fmaf(0.f, k2, mk2));   // what a "priority 0" node added above
+        for (int c = 0; c < nchg; ++c) {
+            const float x0 = (float)rec[8 * c + 6] * __builtin_amdgcn_rcpf((float)(tab[c * 64 + ls] - thr) + epsf);
+            a1 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2)) - ez;
+        }
+        float tot = (float)((a0 + a1) + (a2 + a3)); if (tot == 0.f) tot = epsf;
+        const double scale = (double)__builtin_amdgcn_rcpf(tot) * inv_a_b2;
+        // -- connected entries: contribution of every second, summed over the seconds (entries are grouped by charger)
+        const int n = SURN()[0];
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const int i = SURIDX()[k];
+            int c = -1;
+            for (int cc = 0; cc < nchg; ++cc) if ((int)rec[8 * cc + 4] == i) c = cc;
+            double e, cs;
+            if (c >= 0) { e = tab[c * 64 + ls]; cs = rec[8 * c + 6]; }
+            else { const D2 p0 = sA[i]; e = fma(sp1, p0.y, p0.x) + thr; cs = (double)sC[i]; }
+            if (on && (SLS()[i] & 1)) {
+                const float x = (float)cs * __builtin_amdgcn_rcpf((float)(e - thr) + epsf);
+                const double ex = (double)__builtin_amdgcn_exp2f(fmaf(x, k2, mk2));
+                const double e_no = fmin(e - cs, thr);                   // min / max as written (WRSN.py:123-124)
+                const double e_with = fmax(e - cs + SURRATE()[k], cap);
+                acc += ex * (e_with - e_no) * scale;
+            }
+            if (k == n - 1 || SURAGENT()[k + 1] != SURAGENT()[k]) {
+                const double r = wv_sum(acc);
+                if (lane == 0) SURACC()[k] += r;
+                acc = 0.0;
+            }
+        }
+        // -- advance the node registers by nb seconds
+        const double dnb = (double)nb;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const double lin = E[j] - dnb * (d1[j] + d2[j]);
+            E[j] = ((cm >> j) & 1u) ? rec[8 * cpos[j] + 5] : lin;
+        }
+        __syncthreads();
+        return true;
+    }
+
     // lane 0: the list update_reward iterates (alive chargers whose action type is "charging", their connected nodes)
     WDEV void ur_build() {
         int n = 0;
@@ -908,7 +1047,18 @@ struct Sim {
             }
             // ---- the steady loop: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge (Node.py:68),
             //      repeated for every whole second taken above; a lone reward item of the generic path runs it once
-            for (int q = 0; q < nrep; ++q) {
+            int q0 = 0;
+#ifdef WRSN_PROFILE
+            if (fused && do_ur) { prof_[16] += 1; prof_[17] += (nrep >= 8); prof_[18] += (nrep >= 32); prof_[19] += (nrep >= 8) ? nrep : 0; prof_[20] += (nrep >= 32) ? nrep : 0; prof_[21] += (SURN()[0] > 0) ? nrep : 0; }
+#endif
+            if (fused && do_ur && SURN()[0] > 0) {
+                while (nrep - q0 >= 8) {                     // batches of up to 64 seconds, one lane per second
+                    const int nb = (nrep - q0 < 64) ? (nrep - q0) : 64;
+                    if (!steady_batch(nb, rrh, any_rr)) break;
+                    q0 += nb;
+                }
+            }
+            for (int q = q0; q < nrep; ++q) {
                 if (fused) {
                     if (any_rr) {
 #pragma unroll
@@ -1635,6 +1785,7 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
 
     for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH) {
         __syncthreads();                                   // pc ready / previous chunk consumed
+#ifndef WRSN_OBS_NO_FILL
         for (int idx = tid; idx < WRSN_OBS_CH * 2 * WRSN_OBS_LD; idx += 256) {
             const int n = idx >> 8, r = idx & 255;         // LD = 128: 256 entries (x row, y row) per node
             const bool isx = r < WRSN_OBS_LD; const int c = r & (WRSN_OBS_LD - 1);
@@ -1647,7 +1798,9 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
             }
             if (isx) A[n * WRSN_OBS_LD + c] = v; else Bm[n * WRSN_OBS_LD + c] = v;
         }
+#endif
         __syncthreads();
+#ifndef WRSN_OBS_NO_MFMA
         if (band) {
 #pragma unroll 4
             for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
@@ -1660,6 +1813,7 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
                 }
             }
         }
+#endif
     }
     // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (band) {
@@ -1701,6 +1855,7 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
         if (tid == 0) tmap[o] = mp;
     }
     __syncthreads();
+#ifndef WRSN_OBS_NO_MAPS234
     for (int idx = tid; idx < G * G; idx += 256) {
         const int i = idx / G, j = idx - i * G;
         float v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -1711,6 +1866,7 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
         }
         out[(size_t)G * G + idx] = v1; out[(size_t)2 * G * G + idx] = v2; out[(size_t)3 * G * G + idx] = v3;
     }
+#endif
 }
 
 static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return NP * 3 * 8 + WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }

@@ -8,7 +8,7 @@ _lib._lib = _lib.bind(C.CDLL(os.path.join(ROOT, "tools", "libwrsn_hip_profile.so
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 NAMES = ["scalar_run", "grid_run", "node_half", "update_reward", "exact_walk", "rebuild_cache", "set_levels", "min_fitness",
          "precheck", "conn_build", "load", "store", "#services", "#fused_s", "#jumped_s", "#generic_items",
-         "item:SL", "item:NC", "item:UR", "item:NA", "item:NB", "item:select", "#trigger_checks", "#irregular_NB"]
+         "#fused_ur_calls", "#calls>=8", "#calls>=32", "sec_in>=8", "sec_in>=32", "sec_with_entries", "#trigger_checks", "#irregular_NB"]
 def prof(env):
     a = np.zeros((env.num_env * 25,), dtype=np.int64)
     _lib.check(env._h.lib, env._h.lib.wrsn_peek(env._h._h, 10, a.ctypes.data))
