@@ -179,6 +179,10 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.tc_idx, B * (size_t)d.CCAP))) break;
         if ((rc = dalloc(h, &d.ncov, B * NP))) break;
         if ((rc = dalloc(h, &d.nflags, B * NP))) break;
+        if ((rc = dalloc(h, &d.nbp, B * NP * 4))) break;
+        if ((rc = dalloc(h, &d.nbp_es, B * NP * 8))) break;
+        if ((rc = dalloc(h, &d.es_bs, B * NP))) break;
+        if ((rc = dalloc(h, &d.tcp, B * (size_t)d.TP * 4))) break;
         if ((rc = alloc_node_arrays(h, &d.live))) break;
         if ((rc = alloc_node_arrays(h, &d.snap))) break;
         if ((rc = dalloc(h, &d.counters, B * 25))) break;

@@ -23,7 +23,17 @@
 #define WRSN_CHG_MAX 8                    // nodes under charge handled by the time-parallel steady batch
 // Diagnostic build only (-DWRSN_PROFILE, tools/build_profile.sh): per-phase cycle totals per environment.  Stamps go
 // to a buffer of their own (WrsnDev.counters) and no output is computed from them; the product build has none.
-#ifdef WRSN_PROFILE
+#if defined(WRSN_PROFILE) && WRSN_PROFILE >= 2
+// level 2: event histogram instead of phase timers (slot = process hop fired; 19.. = service kinds)
+#define WRSN_PROF_DECL long long prof_[24]; long long prof_t_;
+#define WRSN_PROF_ZERO for (int q_ = 0; q_ < 24; ++q_) prof_[q_] = 0;
+#define WRSN_PROF_MARK(var)
+#define WRSN_PROF_SPAN(slot, a, b)
+#define WRSN_PROF_T0
+#define WRSN_PROF_ADD(slot)
+#define WRSN_PROF_CNT(slot, v)
+#define WRSN_PROF_EV(slot, v) prof_[slot] += (v);
+#elif defined(WRSN_PROFILE)
 #define WRSN_PROF_DECL long long prof_[24]; long long prof_t_;
 #define WRSN_PROF_ZERO for (int q_ = 0; q_ < 24; ++q_) prof_[q_] = 0;
 #define WRSN_PROF_MARK(var) const long long var = clock64();
@@ -31,6 +41,7 @@
 #define WRSN_PROF_T0 const long long pt0_ = clock64();
 #define WRSN_PROF_ADD(slot) prof_[slot] += clock64() - pt0_;
 #define WRSN_PROF_CNT(slot, v) prof_[slot] += (v);
+#define WRSN_PROF_EV(slot, v)
 #else
 #define WRSN_PROF_DECL
 #define WRSN_PROF_ZERO
@@ -39,6 +50,7 @@
 #define WRSN_PROF_CNT(slot, v)
 #define WRSN_PROF_MARK(var)
 #define WRSN_PROF_SPAN(slot, a, b)
+#define WRSN_PROF_EV(slot, v)
 #endif
 // profile slots: 0 scalar_run  1 grid_run  2 node_half(fast)  3 update_reward  4 exact_walk  5 rebuild_cache  6 set_levels
 //                7 min_fitness 8 precheck  9 conn_build  10 load  11 store  12 #services  13 #fused seconds  14 #jumped seconds  15 #generic items
@@ -158,6 +170,31 @@ WDEV double fast_rcp(double x) {
 }
 
 // ------------------------------------------------------------------ the per-environment simulator
+// ------------------------------------------------------------------ LDS gathers
+// Eight data-dependent LDS words in ONE round trip: the ds_read are issued back to back and waited for once.  Written
+// as inline assembly because the register-pressure heuristics of the scheduler otherwise emit read / wait / use eight
+// times in a row (the graph sweeps below spent most of their time in exactly that).
+#ifndef WRSN_LDS_GATHER_DEFINED
+WDEV void wrsn_lds_gather8_b32(const int32_t* base, const int (&idx)[8], int (&out)[8]) {
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (uint32_t)(uintptr_t)(base + idx[k]);      // low half of a flat LDS address = LDS offset
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %9\n\tds_read_b32 %2, %10\n\tds_read_b32 %3, %11\n\t"
+                 "ds_read_b32 %4, %12\n\tds_read_b32 %5, %13\n\tds_read_b32 %6, %14\n\tds_read_b32 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+}
+WDEV void wrsn_lds_gather8_b64(const double* base, const int (&idx)[8], double (&out)[8]) {
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = (uint32_t)(uintptr_t)(base + idx[k]);
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                 "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]), "=&v"(out[7])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+}
+#endif
+
 template <int NPL>
 struct Sim {
     // identity / geometry.  Pointers are not kept as members: they are derived on demand from the device descriptor
@@ -181,6 +218,7 @@ struct Sim {
     double last_minfit;
     WRSN_PROF_DECL
 
+    struct alignas(16) U4 { uint32_t x, y, z, w; };
     // lane-0 bookkeeping of the scalar event processor lives in LDS, not in registers
     struct Scalar { double ev_time, ev2_time; int64_t ev_seq, n_events; int32_t L, pend, pend_idx, ev_valid, ev_kind, ev_idx, ev_prio, ev_uf; };
     static_assert(sizeof(Scalar) == WRSN_LDS_SCALAR_BYTES, "wrsn_lds_bytes must match");
@@ -198,7 +236,11 @@ struct Sim {
     WDEV const int32_t* TC_OFF() const { return dp->tc_off + (size_t)env * (dp->TP + 1); }
     WDEV const int32_t* TC_IDX() const { return dp->tc_idx + (size_t)env * dp->CCAP; }
     WDEV const int32_t* NCOV() const { return dp->ncov + (size_t)env * NP; }
-    WDEV const int32_t* NFLAGS() const { return dp->nflags + (size_t)env * NP; }
+    WDEV const int32_t* NFLAGS() const { return dp->nflags + (size_t)env * NP; }   // bit 0 direct node, bit 1 more than 8 neighbours, bits 8.. len(listTargets)
+    WDEV const U4* NBP() const { return (const U4*)(dp->nbp + (size_t)env * NP * 4); }
+    WDEV const double* NBP_ES() const { return dp->nbp_es + (size_t)env * NP * 8; }
+    WDEV const double* ES_BS() const { return dp->es_bs + (size_t)env * NP; }
+    WDEV const U4* TCP() const { return (const U4*)(dp->tcp + (size_t)env * dp->TP * 4); }
     WDEV double* RING() const { return (use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP; }
     WDEV double* LOGBUF() const { return (use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP; }
     // ---- LDS carve-up (must match wrsn_lds_bytes)
@@ -244,39 +286,74 @@ struct Sim {
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
 
-    // -------------------------------------------------------------- neighbour ids of the lane's nodes (static topology)
-    // 8 ids of 16 bit per node slot (0xFFFF = none), id order; loaded only by the two routines that sweep the graph.
+    // -------------------------------------------------------------- static graph data of the lane's nodes
+    // Neighbour lists are sorted by (distance, id) when the topology is built, so Node.find_receiver (Node.py:92-100:
+    // the first strictly nearer candidate in id order) is "the first eligible neighbour".  The eight nearest ids of a
+    // node are packed 16 bit each (0xFFFF = none) next to the send cost of that hop; nodes with more neighbours (or
+    // NPL > 6, where the ids would not fit the register file) walk the sorted CSR lists instead.  A routine that sweeps
+    // the graph loads these once (independent 16-byte loads) and then only touches LDS.
     static constexpr bool kNbReg = (NPL <= 6);
-    struct NbRegs { uint32_t p[kNbReg ? NPL : 1][4]; unsigned ovf; };
+    struct NbRegs { uint32_t p[kNbReg ? NPL : 1][4]; unsigned ovf, direct; int ncov[NPL]; };
     WDEV void load_neighbors(NbRegs& nb) const {
-        nb.ovf = 0;
-        if (kNbReg) {
-            const int32_t* off = NB_OFF(); const int32_t* idx = NB_IDX();
+        nb.ovf = 0; nb.direct = 0;
 #pragma unroll
-            for (int j = 0; j < (kNbReg ? NPL : 1); ++j) {
-                const int i = j * 64 + lane;
-                const int p0 = off[i], p1 = off[i + 1];
-                if (p1 - p0 > 8) nb.ovf |= 1u << j;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    uint32_t lo = (p0 + 2 * w < p1) ? (uint32_t)idx[p0 + 2 * w] : 0xFFFFu;
-                    uint32_t hi = (p0 + 2 * w + 1 < p1) ? (uint32_t)idx[p0 + 2 * w + 1] : 0xFFFFu;
-                    nb.p[j][w] = lo | (hi << 16);
-                }
-            }
+        for (int j = 0; j < NPL; ++j) {
+            const int i = j * 64 + lane;
+            const int f = NFLAGS()[i];
+            nb.direct |= (unsigned)(f & 1) << j; nb.ncov[j] = f >> 8;
+            if (kNbReg) {
+                nb.ovf |= (unsigned)((f >> 1) & 1) << j;
+                const U4 v = NBP()[i];
+                nb.p[kNbReg ? j : 0][0] = v.x; nb.p[kNbReg ? j : 0][1] = v.y; nb.p[kNbReg ? j : 0][2] = v.z; nb.p[kNbReg ? j : 0][3] = v.w;
+            } else nb.ovf |= 1u << j;
         }
     }
-    // visit the neighbours of own node slot j (node i)
-#define WRSN_FOR_NEIGHBORS(nbr, j, i, nbvar, body)                                                 \
-    if (kNbReg && !(((nbr).ovf >> (j)) & 1u)) {                                                    \
-        _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                                         \
-            const uint32_t pk_ = (nbr).p[kNbReg ? (j) : 0][w_];                                    \
-            { const int nbvar = (int)(pk_ & 0xFFFFu); if (nbvar != 0xFFFF) { body } }              \
-            { const int nbvar = (int)(pk_ >> 16); if (nbvar != 0xFFFF) { body } }                  \
-        }                                                                                          \
-    } else {                                                                                       \
-        const int32_t* off_ = NB_OFF(); const int32_t* idx_ = NB_IDX();                            \
-        for (int p_ = off_[i]; p_ < off_[(i) + 1]; ++p_) { const int nbvar = idx_[p_]; body }      \
+    // eight packed ids -> indices (`self` where the slot is empty) and a validity mask
+    WDEV static unsigned unpack8(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int self, int (&idx)[8]) {
+        const uint32_t pk[4] = {p0, p1, p2, p3}; unsigned ok = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int lo = (int)(pk[w] & 0xFFFFu), hi = (int)(pk[w] >> 16);
+            ok |= (unsigned)(lo < 0xFFFE) << (2 * w); ok |= (unsigned)(hi < 0xFFFE) << (2 * w + 1);
+            idx[2 * w] = (lo < 0xFFFE) ? lo : self; idx[2 * w + 1] = (hi < 0xFFFE) ? hi : self;
+        }
+        return ok;
+    }
+    // neighbours of node i beyond the packed ones / for NPL > 6: the sorted CSR list
+#define WRSN_FOR_NEIGHBORS_CSR(i, nbvar, body)                                                     \
+    { const int32_t* off_ = NB_OFF(); const int32_t* idx_ = NB_IDX();                              \
+      for (int p_ = off_[i]; p_ < off_[(i) + 1]; ++p_) { const int nbvar = idx_[p_]; body } }
+
+    // nodes covering target t: the first eight ids are packed like the neighbour ids (0xFFFE in the last slot: more
+    // than eight, walk the CSR list).  Returns the validity mask, 0xFFFFFFFF for "use the CSR list".
+    WDEV unsigned covering8(int t, int (&idx)[8]) const {
+        const U4 v = TCP()[t];
+        if ((v.w >> 16) == 0xFFFEu) return 0xFFFFFFFFu;
+        return unpack8(v.x, v.y, v.z, v.w, 0, idx);
+    }
+
+    // Node.find_receiver (Node.py:92-100) of node i from its packed neighbour words: the nearest alive neighbour whose
+    // level is lower than lvl, -1 if none; *es = energy of sending one packet to it (Node.py:114-115)
+    WDEV int find_receiver(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, bool ovf, int i, int lvl, double* es) const {
+        int r = -1;
+        if (kNbReg && !ovf) {
+            int wsel = 0; int idx[8], l2[8];
+            const unsigned ok = unpack8(p0, p1, p2, p3, i, idx);
+            wrsn_lds_gather8_b32(SLS(), idx, l2);
+#pragma unroll
+            for (int k = 7; k >= 0; --k) {                   // nearest last, so that plain selects keep the nearest
+                const int e = (int)((ok >> k) & 1u) & l2[k] & (int)(((l2[k] >> 1) - 1) < lvl);
+                r = (e & 1) ? idx[k] : r; wsel = (e & 1) ? k : wsel;
+            }
+            *es = (r >= 0) ? NBP_ES()[(size_t)i * 8 + wsel] : 0.0;
+        } else {
+            *es = 0.0;
+            for (int p = NB_OFF()[i]; p < NB_OFF()[i + 1]; ++p) {
+                const int nb = NB_IDX()[p]; const int l2 = SLS()[nb];
+                if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) { r = nb; *es = e_send(NB_DIST()[p]); break; }
+            }
+        }
+        return r;
     }
 
     // -------------------------------------------------------------- state load / store
@@ -357,26 +434,30 @@ struct Sim {
             int i = j * 64 + lane;
             int ls = SLS()[i]; oldlv[j] = (ls >> 1) - 1;
             int al = ls & 1;
-            int lv = (al && (NFLAGS()[i] & 1)) ? 1 : -1;
+            int lv = (al && ((nbr.direct >> j) & 1u)) ? 1 : -1;
             SLS()[i] = ((lv + 1) << 1) | al;                   // own entry only
         }
         __syncthreads();
+        // breadth-first levels.  A node found in sweep `cur` gets level cur + 1 in place: a reader of the same sweep
+        // looks for level == cur and is not affected by seeing either the old (-1) or the new value.
         for (int cur = 1; cur <= N; ++cur) {
-            bool ch = false; int newls[NPL];
+            bool ch = false;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                int i = j * 64 + lane;
-                int ls = SLS()[i]; newls[j] = ls;
-                if ((ls & 1) && (ls >> 1) == 0) {           // alive, level == -1
-                    bool hit = false;
-                    WRSN_FOR_NEIGHBORS(nbr, j, i, nb, { const int l2 = SLS()[nb]; if ((l2 & 1) && ((l2 >> 1) - 1) == cur) hit = true; })
-                    if (hit) { newls[j] = ((cur + 2) << 1) | 1; ch = true; }
-                }
+                const int i = j * 64 + lane;
+                const int ls = SLS()[i];
+                int hit = 0;
+                if (kNbReg && !((nbr.ovf >> j) & 1u)) {
+                    int idx[8], l2[8];
+                    const unsigned ok = unpack8(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], i, idx);
+                    wrsn_lds_gather8_b32(SLS(), idx, l2);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) hit |= (int)((ok >> k) & 1u) & l2[k] & (int)(((l2[k] >> 1) - 1) == cur);
+                } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { const int l2 = SLS()[nb]; hit |= l2 & (int)(((l2 >> 1) - 1) == cur); })
+                if ((ls & 1) && (ls >> 1) == 0 && (hit & 1)) { SLS()[i] = ((cur + 2) << 1) | 1; ch = true; }   // alive, level == -1
             }
             __syncthreads();
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) SLS()[j * 64 + lane] = newls[j];
-            __syncthreads();
+            WRSN_PROF_CNT(21, 1)
             if (!wv_any(ch)) break;
         }
         bool changed = false;
@@ -385,9 +466,14 @@ struct Sim {
         if (wv_any(changed)) cache_dirty = 1;
         bool bad = false;
         for (int t = lane; t < T; t += 64) {
-            bool act = false;
-            for (int p = TC_OFF()[t]; p < TC_OFF()[t + 1]; ++p) if ((SLS()[TC_IDX()[p]] >> 1) >= 2) act = true;   // covered by a reached node
-            if (!act) bad = true;
+            int acti = 0; int idx[8];                       // covered by a reached node?
+            const unsigned ok = covering8(t, idx);
+            if (ok != 0xFFFFFFFFu) {
+                int l2[8]; wrsn_lds_gather8_b32(SLS(), idx, l2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acti |= (int)((ok >> k) & 1u) & (int)((l2[k] >> 1) >= 2);
+            } else for (int p = TC_OFF()[t]; p < TC_OFF()[t + 1]; ++p) acti |= (int)((SLS()[TC_IDX()[p]] >> 1) >= 2);
+            if (!acti) bad = true;
         }
         alive = wv_any(bad) ? 0 : 1;
         levels_dirty = 0;
@@ -400,27 +486,18 @@ struct Sim {
     WDEV void rebuild_cache() { WRSN_PROF_T0
         int32_t* c1 = (int32_t*)SU(); int32_t* c2 = c1 + NP;
         double es[NPL]; int rc[NPL];
-        const double er = EC()->e_recv, com = EC()->com_range;
+        const double er = EC()->e_recv;
+        NbRegs nbr; load_neighbors(nbr);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             int ls = SLS()[i]; int lvl = (ls >> 1) - 1;
-            int r = -1; double dd = 0.0;
-            if (ls & 1) {
-                if (DBS()[i] > com) {
-                    double bd = 0.0;
-                    for (int p = NB_OFF()[i]; p < NB_OFF()[i + 1]; ++p) {
-                        int nb = NB_IDX()[p]; int l2 = SLS()[nb];
-                        if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) {
-                            double dist = NB_DIST()[p];
-                            if (r < 0 || dist < bd) { r = nb; bd = dist; }
-                        }
-                    }
-                    dd = bd;
-                } else { r = -2; dd = DBS()[i]; }
-            }
-            es[j] = (r != -1) ? e_send(dd) : 0.0; rc[j] = r;
+            int r = -1; double e1 = 0.0;
+            if ((nbr.direct >> j) & 1u) { r = -2; e1 = ES_BS()[i]; }
+            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, lvl, &e1);
+            if (!(ls & 1)) { r = -1; e1 = 0.0; }
+            es[j] = (r != -1) ? e1 : 0.0; rc[j] = r;
             SRCV()[i] = r; c1[i] = 0; c2[i] = 0;
         }
         __syncthreads();
@@ -428,7 +505,7 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             if (((am >> j) & 1u) && rc[j] >= 0) {
-                int n = NCOV()[i];
+                int n = nbr.ncov[j];
                 if (n > 0) {
                     int a = rc[j], guard = 0;
                     while (a >= 0 && guard++ < N) { atomicAdd((i < a) ? &c1[a] : &c2[a], n); a = SRCV()[a]; }
@@ -442,7 +519,7 @@ struct Sim {
             int i = j * 64 + lane;
             if ((am >> j) & 1u) {
                 d1[j] = (double)c1[i] * (er + es[j]);
-                d2[j] = (double)c2[i] * (er + es[j]) + (double)NCOV()[i] * es[j];
+                d2[j] = (double)c2[i] * (er + es[j]) + (double)nbr.ncov[j] * es[j];
                 opm = fmax(opm, es[j]);
             } else { d1[j] = 0.0; d2[j] = 0.0; }
         }
@@ -459,27 +536,27 @@ struct Sim {
     // 1) and only the single source whose packets may hit a starving node is walked packet by packet on lane 0.
     struct WalkRec { double E; int32_t rcv; float es; };      // LDS record for the packet-by-packet walk
 
-    WDEV int live_receiver(int i, double* dd) {               // Node.find_receiver with live status (stale levels)
-        int lvl = (SLS()[i] >> 1) - 1; int r = -1; double bd = 0.0;
-        for (int p = NB_OFF()[i]; p < NB_OFF()[i + 1]; ++p) {
-            int nb = NB_IDX()[p]; int l2 = SLS()[nb];
-            if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) { double dist = NB_DIST()[p]; if (r < 0 || dist < bd) { r = nb; bd = dist; } }
-        }
-        *dd = bd; return r;
+    WDEV int live_receiver(int i, double* es) {               // Node.find_receiver of an arbitrary node (lane 0, after a death)
+        const int lvl = (SLS()[i] >> 1) - 1;
+        const bool ovf = !kNbReg || ((NFLAGS()[i] >> 1) & 1);
+        U4 v; v.x = v.y = v.z = v.w = 0xFFFFFFFFu;
+        if (!ovf) v = NBP()[i];
+        return find_receiver(v.x, v.y, v.z, v.w, ovf, i, lvl, es);
     }
 
     // receivers + send cost of every alive node for the current (live status, last levels); returns max op cost
-    WDEV double walk_receivers(double (&es)[NPL]) {
-        const double com = EC()->com_range; double opm = EC()->e_recv;
+    WDEV double walk_receivers(const NbRegs& nbr, double (&es)[NPL]) {
+        double opm = EC()->e_recv;
         __syncthreads();
         int rc[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane; int r = -1; double dd = 0.0;
-            if (SLS()[i] & 1) {
-                if (DBS()[i] > com) r = live_receiver(i, &dd); else { r = -2; dd = DBS()[i]; }
-            }
-            es[j] = (r != -1) ? e_send(dd) : 0.0; rc[j] = r;
+            int i = j * 64 + lane; int r = -1; double e1 = 0.0;
+            const int ls = SLS()[i];
+            if ((nbr.direct >> j) & 1u) { r = -2; e1 = ES_BS()[i]; }
+            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, (ls >> 1) - 1, &e1);
+            if (!(ls & 1)) { r = -1; e1 = 0.0; }
+            es[j] = (r != -1) ? e1 : 0.0; rc[j] = r;
             opm = fmax(opm, es[j]);
         }
         __syncthreads();
@@ -490,16 +567,17 @@ struct Sim {
     }
 
     // sources [a, b) in closed form.  Returns false (nothing changed) when some node might be unable to pay.
-    WDEV bool walk_range(int a, int b, const double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL], double margin) {
+    WDEV bool walk_range(int a, int b, const NbRegs& nbr, const double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL], double margin) {
         int32_t* c1 = (int32_t*)SU(); int32_t* c2 = c1 + NP;
         const double er = EC()->e_recv;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) { c1[j * 64 + lane] = 0; c2[j * 64 + lane] = 0; }
         __syncthreads();
-        for (int q0 = a; q0 < b; q0 += 64) {
-            const int q = q0 + lane;
-            if (q < b && (SLS()[q] & 1)) {
-                const int n = NCOV()[q]; int v = SRCV()[q], guard = 0;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int q = j * 64 + lane;
+            if (q >= a && q < b && ((am >> j) & 1u)) {
+                const int n = nbr.ncov[j]; int v = SRCV()[q], guard = 0;
                 if (n > 0) while (v >= 0 && guard++ < N) { atomicAdd((q < v) ? &c1[v] : &c2[v], n); v = SRCV()[v]; }
             }
         }
@@ -515,8 +593,8 @@ struct Sim {
                 if (c1[i] > 0 && e - thr < margin) unsafe = true;
                 if (i >= a && i < b) {                             // the node wakes inside this range (Node.py:60)
                     double e2 = fmin(e + rrh[j], cap); gn[j] = e2 - e; e = e2;
-                    e -= (double)c2[i] * per + (double)NCOV()[i] * es[j];
-                    if ((c2[i] > 0 || (NCOV()[i] > 0 && es[j] > 0.0)) && e - thr < margin) unsafe = true;
+                    e -= (double)c2[i] * per + (double)nbr.ncov[j] * es[j];
+                    if ((c2[i] > 0 || (nbr.ncov[j] > 0 && es[j] > 0.0)) && e - thr < margin) unsafe = true;
                 } else if (c2[i] > 0) {
                     e -= (double)c2[i] * per;
                     if (e - thr < margin) unsafe = true;
@@ -549,15 +627,15 @@ struct Sim {
         if (lane == 0) {
             int deaths = 0;
             if (SLS()[q] & 1) {
-                const int nc = NCOV()[q];
+                const int nc = NFLAGS()[q] >> 8;
                 for (int p = 0; p < nc; ++p) {
                     int cur = q;
                     for (int hop = 0; hop <= N; ++hop) {
                         WalkRec w = rec[cur];
                         int r; double esv;
                         if (deaths == 0) { r = w.rcv; esv = (double)w.es; }
-                        else if (NFLAGS()[cur] & 1) { r = -2; esv = e_send(DBS()[cur]); }
-                        else { double dd; r = live_receiver(cur, &dd); esv = (r >= 0) ? e_send(dd) : 0.0; }
+                        else if (NFLAGS()[cur] & 1) { r = -2; esv = ES_BS()[cur]; }
+                        else r = live_receiver(cur, &esv);
                         if (r == -1) { if (w.E <= thr) { SLS()[cur] &= ~1; deaths++; } break; }
                         if (w.E - thr < esv) { rec[cur].E = thr; SLS()[cur] &= ~1; deaths++; break; }
                         double e = w.E - esv;
@@ -587,17 +665,19 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) { e_start[j] = E[j]; gain[j] = 0.0; }
         double margin = 0.0;
         bool any_death = false, need_recv = true;
+        NbRegs nbr; load_neighbors(nbr);
         int a = 0, w = 64;
         for (int guard = 0; a < N && guard < 4 * N + 64; ++guard) {
-            if (need_recv) { margin = 2.0 * walk_receivers(es); need_recv = false; }   // (re-)route for the live status
+            if (need_recv) { WRSN_PROF_MARK(t0_) margin = 2.0 * walk_receivers(nbr, es); need_recv = false; WRSN_PROF_MARK(t1_) WRSN_PROF_SPAN(16, t0_, t1_) }   // (re-)route for the live status
             const int b = (a + w < N) ? a + w : N;
-            if (walk_range(a, b, es, rrh, gain, margin)) {
+            WRSN_PROF_MARK(t2_) const bool ok_ = walk_range(a, b, nbr, es, rrh, gain, margin); WRSN_PROF_MARK(t3_) WRSN_PROF_SPAN(17, t2_, t3_) WRSN_PROF_CNT(18, 1)
+            if (ok_) {
                 a = b;
                 if ((a & 63) == 0) w = 64; else if ((a & 7) == 0 && w < 8) w = 8;   // widen again at aligned boundaries
             } else if (w > 1) {
                 w = (w == 64) ? 8 : 1;                       // somebody may starve in [a, b): look closer
             } else {
-                const int deaths = walk_single(a, es, rrh, gain);
+                WRSN_PROF_MARK(t4_) const int deaths = walk_single(a, es, rrh, gain); WRSN_PROF_MARK(t5_) WRSN_PROF_SPAN(19, t4_, t5_) WRSN_PROF_CNT(20, 1)
                 if (deaths > 0) {
                     any_death = true; need_recv = true;      // everything behind the dead node is re-routed
 #pragma unroll
@@ -742,7 +822,7 @@ struct Sim {
     // wave reduction per charger.  Returns false (nothing done) when more than WRSN_CHG_MAX nodes are being charged.
     struct alignas(16) D2 { double x, y; };
     struct alignas(8) F2 { float x, y; };
-    WDEV bool steady_batch(int nb, const double (&rrh)[NPL], bool any_rr) {
+    WDEV bool steady_batch(int nb, const double (&rrh)[NPL], bool any_rr) { WRSN_PROF_T0
         D2* sA = (D2*)SU(); float* sC = SCSF();
         double* rec = SCHGREC(); double* tab = SCHGTAB();
         const float epsf = 1e-9f;
@@ -863,6 +943,7 @@ struct Sim {
             E[j] = ((cm >> j) & 1u) ? rec[8 * cpos[j] + 5] : lin;
         }
         __syncthreads();
+        WRSN_PROF_ADD(2)
         return true;
     }
 
@@ -902,7 +983,7 @@ struct Sim {
             int i = j * 64 + lane;
             bool al = (am >> j) & 1u;
             lt[j] = al ? ((CS[j] == 0.0) ? WRSN_INF : (E[j] - thr) / CS[j]) : 0.0;
-            tc[j] = (al && (NFLAGS()[i] & 1)) ? lt[j] : -1.0;
+            tc[j] = (al && ((nbr.direct >> j) & 1u)) ? lt[j] : -1.0;
             t[i] = tc[j];
         }
         __syncthreads();
@@ -910,26 +991,35 @@ struct Sim {
         // in the same sweep: fewer sweeps than Jacobi, one barrier per sweep
         unsigned nd = 0;                                     // non-direct alive slots of this lane
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) if (((am >> j) & 1u) && !(NFLAGS()[j * 64 + lane] & 1)) nd |= 1u << j;
+        for (int j = 0; j < NPL; ++j) if (((am >> j) & 1u) && !((nbr.direct >> j) & 1u)) nd |= 1u << j;
         for (int it = 0; it <= N; ++it) {
             bool ch = false;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
-                int i = j * 64 + lane;
-                if ((nd >> j) & 1u) {
-                    double best = -1.0;
-                    WRSN_FOR_NEIGHBORS(nbr, j, i, nb, { best = fmax(best, t[nb]); })      // dead / unreached neighbours hold -1
-                    double cand = fmin(lt[j], best);
-                    if (cand > tc[j]) { tc[j] = cand; t[i] = cand; ch = true; }
-                }
+                const int i = j * 64 + lane;
+                double best = -1.0;                         // dead / unreached neighbours hold -1
+                if (kNbReg && !((nbr.ovf >> j) & 1u)) {
+                    int idx[8]; double tn[8];
+                    const unsigned ok = unpack8(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], i, idx);
+                    wrsn_lds_gather8_b64(t, idx, tn);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) best = fmax(best, ((ok >> k) & 1u) ? tn[k] : -1.0);
+                } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { best = fmax(best, t[nb]); })
+                const double cand = fmin(lt[j], best);
+                if (((nd >> j) & 1u) && cand > tc[j]) { tc[j] = cand; t[i] = cand; ch = true; }
             }
             __syncthreads();
             if (!wv_any(ch)) break;
         }
         double mn = WRSN_INF;
         for (int q = lane; q < T; q += 64) {
-            double v = 0.0;
-            for (int p = TC_OFF()[q]; p < TC_OFF()[q + 1]; ++p) v = fmax(v, t[TC_IDX()[p]]);
+            double v = 0.0; int idx[8];
+            const unsigned ok = covering8(q, idx);
+            if (ok != 0xFFFFFFFFu) {
+                double tn[8]; wrsn_lds_gather8_b64(t, idx, tn);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v = fmax(v, ((ok >> k) & 1u) ? tn[k] : 0.0);
+            } else for (int p = TC_OFF()[q]; p < TC_OFF()[q + 1]; ++p) v = fmax(v, t[TC_IDX()[p]]);
             mn = fmin(mn, v);
         }
         mn = wv_min(mn);
@@ -1048,9 +1138,6 @@ struct Sim {
             // ---- the steady loop: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge (Node.py:68),
             //      repeated for every whole second taken above; a lone reward item of the generic path runs it once
             int q0 = 0;
-#ifdef WRSN_PROFILE
-            if (fused && do_ur) { prof_[16] += 1; prof_[17] += (nrep >= 8); prof_[18] += (nrep >= 32); prof_[19] += (nrep >= 8) ? nrep : 0; prof_[20] += (nrep >= 32) ? nrep : 0; prof_[21] += (SURN()[0] > 0) ? nrep : 0; }
-#endif
             if (fused && do_ur && SURN()[0] > 0) {
                 while (nrep - q0 >= 8) {                     // batches of up to 64 seconds, one lane per second
                     const int nb = (nrep - q0 < 64) ? (nrep - q0) : 64;
@@ -1185,6 +1272,7 @@ struct Sim {
                 return;
             }
         }
+        WRSN_PROF_EV(0, (mt > 3.0 && SAG()[a].type_charging && SAG()[a].n_conn > 0) ? 1 : 0) WRSN_PROF_EV(18, (mt > 3.0 && !agent_single(a, ti)) ? 1 : 0)
         th_sched(ti, PC_MSTEP_INIT, WRSN_URGENT, now);
     }
 
@@ -1259,6 +1347,7 @@ struct Sim {
     WDEV int thread_fire(int ti) {
         const int a = STH()[ti].agent;
         if (STH()[ti].ff != 0) ff_apply(ti, now, true);        // the resume event: every virtual sub-step precedes it
+        WRSN_PROF_EV(STH()[ti].pc, 1)
         switch (STH()[ti].pc) {
         case PC_P_INIT:                                      // MobileCharger.py:105-115: needs the O(N) sum
             for (int i = 0; i < 2 * M; ++i) if (i != ti && STH()[i].agent == a) ff_fallback(i);   // a second process on this charger
@@ -1421,12 +1510,14 @@ struct Sim {
                 // the reward entry list is only needed by a grid service: (re)build it lazily
                 SS()->ev_uf = ur_flags();
                 if (SS()->ev_uf & 1) ur_build(); else SURN()[0] = 0;
+                WRSN_PROF_EV(21, 1) WRSN_PROF_EV(23, SURN()[0])
             }
             if (have_grid && gt < t_lim) {
                 const int uf = SS()->ev_uf;
                 if (uf & 2) { ff_sync_all(gt); ur_build(); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
                 else *arg = 0;
                 *t_lim_out = t_lim; *flags_out = uf & 1;
+                WRSN_PROF_EV(19, 1) WRSN_PROF_EV(20, (uf & 2) ? 1 : 0)
                 SS()->pend = REQ_GRID; return REQ_GRID;
             }
             if (use_limit && !(have_ev && bt < limit)) { now = limit; return REQ_STOP; }
@@ -1434,6 +1525,7 @@ struct Sim {
                 const int uf = SS()->ev_uf;
                 if (uf & 2) { ff_sync_all(gt); ur_build(); }
                 *arg = 1; *t_lim_out = t_lim; *flags_out = uf & 1;
+                WRSN_PROF_EV(22, 1)
                 SS()->pend = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
             }
             now = bt; SS()->n_events++; SS()->ev_valid = 0;
@@ -1676,6 +1768,11 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     double* nb_dist = d.nb_dist + (size_t)env * d.ECAP;
     int32_t *tc_off = d.tc_off + (size_t)env * (d.TP + 1), *tc_idx = d.tc_idx + (size_t)env * d.CCAP;
     int32_t *ncov = d.ncov + nb, *nflags = d.nflags + nb;
+    uint32_t* nbp = d.nbp + nb * 4; double* nbp_es = d.nbp_es + nb * 8; double* es_bs = d.es_bs + nb;
+    uint32_t* tcp = d.tcp + (size_t)env * d.TP * 4;
+    // energy of sending one packet over distance dd (Node.py:114-115), the formula of Sim::e_send
+    const double d0_ = sqrt(ec->efs / ec->emp);
+    auto e_send_t = [&](double dd) { const double dq = dd * dd; return ((dd <= d0_) ? (ec->et + ec->efs * dq) : (ec->et + ec->emp * (dq * dq))) * ec->package_size; };
     const double bx = ec->bs[0], by = ec->bs[1], com = ec->com_range, sen = ec->sen_range;
     int error = 0;
     // frame over nodes and the base station
@@ -1685,11 +1782,12 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
             double x = nx[i], y = ny[i];
             x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y);
             double db = dist2(bx, by, x, y);
-            dbs[i] = db; nflags[i] = (db <= com) ? 1 : 0;
-        } else { dbs[i] = 0.0; nflags[i] = 0; }
+            dbs[i] = db; nflags[i] = (db <= com) ? 1 : 0; es_bs[i] = e_send_t(db);
+        } else { dbs[i] = 0.0; nflags[i] = 0; es_bs[i] = 0.0; }
     }
     x0 = wv_min(x0); x1 = wv_max(x1); y0 = wv_min(y0); y1 = wv_max(y1);
-    // neighbour lists, id order
+    // neighbour lists sorted by (distance, id): Node.find_receiver (Node.py:92-100) keeps the first strictly nearer
+    // candidate in id order, which is the minimum of (distance, id) over the candidates
     int base = 0;
     for (int i0 = 0; i0 < NP; i0 += 64) {
         int i = i0 + lane; int cnt = 0;
@@ -1699,7 +1797,24 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
         nb_off[i] = off;
         if (i < N && off + cnt <= d.ECAP) {
             int p = off;
-            for (int k = 0; k < N; ++k) { double dd = dist2(nx[k], ny[k], nx[i], ny[i]); if (k != i && dd <= com) { nb_idx[p] = k; nb_dist[p] = dd; ++p; } }
+            for (int k = 0; k < N; ++k) {
+                double dd = dist2(nx[k], ny[k], nx[i], ny[i]);
+                if (k != i && dd <= com) {
+                    int q = p;                               // insertion keeps equal distances in id order
+                    while (q > off && nb_dist[q - 1] > dd) { nb_idx[q] = nb_idx[q - 1]; nb_dist[q] = nb_dist[q - 1]; --q; }
+                    nb_idx[q] = k; nb_dist[q] = dd; ++p;
+                }
+            }
+        }
+        if (i < NP) {
+            const bool fits = i < N && off + cnt <= d.ECAP;
+            for (int w = 0; w < 4; ++w) {
+                uint32_t lo = (fits && 2 * w < cnt) ? (uint32_t)nb_idx[off + 2 * w] : 0xFFFFu;
+                uint32_t hi = (fits && 2 * w + 1 < cnt) ? (uint32_t)nb_idx[off + 2 * w + 1] : 0xFFFFu;
+                nbp[i * 4 + w] = lo | (hi << 16);
+            }
+            for (int w = 0; w < 8; ++w) nbp_es[i * 8 + w] = (fits && w < cnt) ? e_send_t(nb_dist[off + w]) : 0.0;
+            if (cnt > 8) nflags[i] |= 2;
         }
         base += __shfl(incl, 63);
     }
@@ -1709,7 +1824,7 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     for (int i = lane; i < NP; i += 64) {
         int c = 0;
         if (i < N) for (int t = 0; t < T; ++t) if (dist2(nx[i], ny[i], tx[t], ty[t]) <= sen) c++;
-        ncov[i] = c;
+        ncov[i] = c; nflags[i] |= c << 8;
     }
     int tbase = 0;
     for (int t0 = 0; t0 < d.TP; t0 += 64) {
@@ -1719,6 +1834,15 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
         int off = tbase + incl - cnt;
         tc_off[t] = off;
         if (t < T && off + cnt <= d.CCAP) { int p = off; for (int k = 0; k < N; ++k) if (dist2(nx[k], ny[k], tx[t], ty[t]) <= sen) tc_idx[p++] = k; }
+        if (t < d.TP) {
+            const bool fits = t < T && off + cnt <= d.CCAP;
+            for (int w = 0; w < 4; ++w) {
+                uint32_t lo = (fits && 2 * w < cnt) ? (uint32_t)tc_idx[off + 2 * w] : 0xFFFFu;
+                uint32_t hi = (fits && 2 * w + 1 < cnt) ? (uint32_t)tc_idx[off + 2 * w + 1] : 0xFFFFu;
+                if (w == 3 && cnt > 8) hi = 0xFFFEu;
+                tcp[t * 4 + w] = lo | (hi << 16);
+            }
+        }
         tbase += __shfl(incl, 63);
     }
     if (lane == 0) tc_off[d.TP] = tbase;

@@ -77,10 +77,14 @@ struct WrsnDev {
     WrsnEnvConst *ec;                 // [B]
     double *node_x, *node_y, *dist_bs;   // [B][NP]
     double *target_x, *target_y;      // [B][TP]
-    int32_t *nb_off, *nb_idx;         // [B][NP+1], [B][ECAP]  Node.neighbors (id order)
+    int32_t *nb_off, *nb_idx;         // [B][NP+1], [B][ECAP]  Node.neighbors sorted by (distance, id)
     double *nb_dist;                  // [B][ECAP]
     int32_t *tc_off, *tc_idx;         // [B][TP+1], [B][CCAP]  target -> covering nodes (id order)
-    int32_t *ncov, *nflags;           // [B][NP]  len(listTargets); bit0: in BaseStation.direct_nodes
+    int32_t *ncov, *nflags;           // [B][NP]  len(listTargets); bit 0: in BaseStation.direct_nodes, bit 1: > 8 neighbours, bits 8..: ncov
+    uint32_t *nbp;                    // [B][NP][4]  the eight nearest neighbour ids, 16 bit each (0xFFFF none), sorted by (distance, id)
+    double *nbp_es;                   // [B][NP][8]  energy of sending one packet to that neighbour
+    double *es_bs;                    // [B][NP]     energy of sending one packet to the base station
+    uint32_t *tcp;                    // [B][TP][4]  the first eight covering node ids of a target, packed alike
     WrsnNodeArrays live, snap;        // current state / post-warm-up snapshot
     int64_t *counters;                // [4]
 };

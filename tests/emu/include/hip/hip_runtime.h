@@ -95,6 +95,10 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_m
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 inline int emu_readlane(int v, int src) { return emu_exchange(v, src); }
 #define __builtin_amdgcn_readlane emu_readlane
+// the LDS gathers of wrsn_sim.h are inline assembly (eight ds_read back to back): plain loads here
+#define WRSN_LDS_GATHER_DEFINED
+inline void wrsn_lds_gather8_b32(const int32_t* base, const int (&idx)[8], int (&out)[8]) { for (int k = 0; k < 8; ++k) out[k] = base[idx[k]]; }
+inline void wrsn_lds_gather8_b64(const double* base, const int (&idx)[8], double (&out)[8]) { for (int k = 0; k < 8; ++k) out[k] = base[idx[k]]; }
 inline int __double2loint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
 inline int __double2hiint(double d) { long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
 inline double __hiloint2double(int hi, int lo) { long long b = ((long long)hi << 32) | (unsigned int)lo; double d; std::memcpy(&d, &b, 8); return d; }
