@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--kernel-steps", type=int, default=20, help="steps of the per-kernel timing pass")
+    ap.add_argument("--step-budget", type=int, default=0,
+                    help="work units one launch may spend per environment (VecWRSN step_budget); 0 = blocking steps")
     args = ap.parse_args()
 
     import torch
@@ -88,7 +90,7 @@ def main():
     scenarios = [synth_scenario(args.seed + env0 + e, N, T) for e in range(B)]
     t_gen = time.time() - t_gen
     t_set = time.time()
-    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True)
+    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=args.step_budget)
     env.synchronize()
     t_set = time.time() - t_set
     stats = RolloutStats(B, M, dev)
@@ -105,7 +107,7 @@ def main():
 
     for _ in range(max(1, args.warmup)):                       # untimed: also loads every torch kernel the timed loop uses
         one_step()
-        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"])
+        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
     stats.buf.zero_()
     torch.cuda.synchronize(dev)
     c0 = env.counters()
@@ -115,7 +117,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"])
+        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
@@ -174,7 +176,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 (physics) / f32 (observation)", "data": "synthetic",
             "config": {"workload": "%d envs/GPU x %d nodes x %d targets x %d MC, random policy U[0,1)^3, auto-reset, 4x%dx%d observation" % (B, N, T, M, G, G),
-                       "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "parallelism": "env-shard x%d" % world},
+                       "step_budget": args.step_budget, "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "parallelism": "env-shard x%d" % world},
             "env_steps_timed": env_steps, "mean_episode_seconds_so_far": float(info_ticks.mean()), "mean_return_table_rows": int(table.shape[0]),
             "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(t_set, 2)},
             "kernels": {"wrsn_step_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},

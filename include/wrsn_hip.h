@@ -76,6 +76,7 @@ typedef struct wrsn_step_out {
     float   *obs;             /* [B,4,G,G] get_state(agent_id) (WRSN.py:130-186); untouched rows for agent_id < 0 */
     int32_t *status;          /* [B]  0 ok; 1 step fell off the end (reference returns None);
                                       2 every charger dead (reference would hang); 3 auto-reset performed;
+                                      4 the step is still in flight (wrsn_set_step_budget), call wrsn_step again;
                                       negative: per-env error (capacity)                           */
 } wrsn_step_out;
 
@@ -131,6 +132,15 @@ int wrsn_reset(wrsn_t *h, const uint8_t *env_mask, const wrsn_step_out *out);
  * and reports status 3 with the reset request (agent 0, reward 0). */
 int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t auto_reset,
               const wrsn_step_out *out);
+
+/* Bound the work one wrsn_step launch spends on an environment (0, the default: every environment runs its
+ * WRSN.step to the end, like the blocking call of the reference).  The duration of a WRSN.step is heavy-tailed (it
+ * runs until the next charger finishes: 1 .. several thousand simulated seconds), so in a batch a launch waits for
+ * its slowest environment.  With a budget (in work units: simulated seconds + 32 per packet-exact second + 4 per
+ * service; deterministic, not wall-clock) an environment whose step is not finished reports status 4 / agent_id -1
+ * and the next wrsn_step goes on with it, ignoring agent_id/action of that row.  Every WRSN.step is still executed
+ * in full and returns exactly the same request; only the launch it is reported in changes. */
+int wrsn_set_step_budget(wrsn_t *h, int32_t work_units);
 
 /* Render get_state(agent) for arbitrary agents (DEVICE int32 [B], < 0 = skip) into obs (DEVICE). */
 int wrsn_render(wrsn_t *h, const int32_t *agent_id, float *obs);

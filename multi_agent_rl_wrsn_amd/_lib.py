@@ -24,7 +24,8 @@ ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max"
 
 # every entry point include/wrsn_hip.h declares
 EXPORTS = ("wrsn_create", "wrsn_destroy", "wrsn_set_stream", "wrsn_set_scenario", "wrsn_reset", "wrsn_step",
-           "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network", "wrsn_last_error",
+           "wrsn_set_step_budget", "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
+           "wrsn_last_error",
            "wrsn_version")
 
 
@@ -71,6 +72,8 @@ def bind(lib):
     lib.wrsn_reset.restype = C.c_int
     lib.wrsn_step.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(WrsnStepOut)]
     lib.wrsn_step.restype = C.c_int
+    lib.wrsn_set_step_budget.argtypes = [vp, C.c_int32]
+    lib.wrsn_set_step_budget.restype = C.c_int
     lib.wrsn_render.argtypes = [vp, vp, vp]
     lib.wrsn_render.restype = C.c_int
     lib.wrsn_peek.argtypes = [vp, C.c_int32, vp]
@@ -181,6 +184,9 @@ class RawHandle:
     def step(self, agent_ptr, action_ptr, auto_reset=False, **out_ptrs):
         o = self._out(**out_ptrs)
         check(self.lib, self.lib.wrsn_step(self._h, C.c_void_p(agent_ptr), C.c_void_p(action_ptr), int(bool(auto_reset)), C.byref(o)))
+
+    def set_step_budget(self, work_units):
+        check(self.lib, self.lib.wrsn_set_step_budget(self._h, int(work_units)))
 
     def render(self, agent_ptr, obs_ptr):
         check(self.lib, self.lib.wrsn_render(self._h, C.c_void_p(agent_ptr), C.c_void_p(obs_ptr)))

@@ -41,6 +41,7 @@ struct wrsn_handle {
     int npl;
     int scenario_set;
     int lds_env, lds_obs;
+    int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     std::vector<void*> allocs;
     int32_t* d_agent_tmp;      // [B] agent ids for rendering when the caller passes no agent_id output
     int32_t* d_reset_agent;    // [B] -1 everywhere: "agent" argument of a reset launch
@@ -87,7 +88,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else hipLaunchKernelGGL(wrsn_step_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                            auto_reset, mask, out)
+                            auto_reset, (mode == WRSN_MODE_STEP) ? h->step_budget : 0, mask, out)
     switch (h->npl) {
     case 1: WRSN_LAUNCH(1); break;
     case 2: WRSN_LAUNCH(2); break;
@@ -147,7 +148,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(WRSN_ERR_ARG, "device ordinal out of range");
     HIPCHK(hipSetDevice(cfg->device));
     wrsn_handle* h = new wrsn_handle();
-    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0;
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0;
     h->npl = npl_for(cfg->n_node);
     if (h->npl < 0) { delete h; return fail(WRSN_ERR_ARG, "n_node too large"); }
     WrsnDev& d = h->dev;
@@ -287,6 +288,12 @@ int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t 
     int rc = launch_env(h, WRSN_MODE_STEP, 0, h->dev.B, agent_id, action, auto_reset, nullptr, o);
     if (rc) return rc;
     if (out->obs) return launch_obs(h, o.agent_id, out->obs);
+    return WRSN_OK;
+}
+
+int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
+    if (!h || work_units < 0) return fail(WRSN_ERR_ARG, "bad step budget");
+    h->step_budget = work_units;
     return WRSN_OK;
 }
 

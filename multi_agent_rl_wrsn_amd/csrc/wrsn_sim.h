@@ -389,7 +389,7 @@ struct Sim {
         WRSN_PROF_ADD(10)
     }
 
-    WDEV void store(const WrsnNodeArrays& a, int terminal_pending, int64_t n_steps_add) { WRSN_PROF_T0
+    WDEV void store(const WrsnNodeArrays& a, int terminal_pending, int64_t n_steps_add, int susp = 0) { WRSN_PROF_T0
         __syncthreads();
         size_t nb = (size_t)env * NP;
 #pragma unroll
@@ -406,7 +406,7 @@ struct Sim {
             dy->net_phase = net_phase; dy->net_active = net_active; dy->node_phase = node_phase; dy->alive = alive;
             dy->levels_dirty = levels_dirty; dy->cache_dirty = cache_dirty; dy->irreg = irreg; dy->ring_len = ring_len;
             dy->ring_head = ring_head; dy->safe_ticks = safe_ticks; dy->frozen = frozen; dy->n_connected = SREQ()[2];
-            dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending;
+            dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending; dy->susp = susp;
         }
         uint64_t* ga = (uint64_t*)dy->ag; const uint64_t* la = (const uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) ga[w] = la[w];
@@ -1553,8 +1553,13 @@ struct Sim {
     }
 
     // drive the environment until the run stops: lane 0 fires charger events, the wave runs the grid and the O(N) services
-    WDEV void run(bool use_limit, double limit) {
+    // `budget` > 0 bounds the work of one launch: ticks simulated + 32 per exact second + 4 per service.  When it is
+    // used up the run is suspended in front of the next grid service (returns true) and the following launch goes on
+    // from the stored state: lane 0 simply takes the same decision again (it has no side effect that is not idempotent).
+    WDEV bool run(bool use_limit, double limit, int budget = 0) {
         double svc = 0.0;
+        const int64_t ticks0 = n_ticks, exact0 = n_exact;
+        bool suspended = false;
         for (long guard = 0; guard < 8000000L; ++guard) {
             { WRSN_PROF_T0
             if (lane == 0) {
@@ -1567,6 +1572,7 @@ struct Sim {
             const int req = SREQ()[0], arg = SREQ()[1];
             now = SREQD()[1]; seq = ((const int64_t*)SREQD())[2];      // lane 0 advanced them while firing events
             if (req == REQ_STOP) break;
+            if (budget > 0 && req == REQ_GRID && (n_ticks - ticks0) + 32 * (n_exact - exact0) + 4 * guard >= (int64_t)budget) { suspended = true; break; }
             switch (req) {
             case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], arg != 0, SREQ()[3] != 0); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { WRSN_PROF_T0 svc = precheck(arg); WRSN_PROF_ADD(8) } break;
@@ -1576,8 +1582,9 @@ struct Sim {
             __syncthreads();
         }
         __syncthreads();
-        if (lane == 0) ff_sync_all(now);                     // bring virtual charger sub-steps up to the return instant
+        if (lane == 0 && !suspended) ff_sync_all(now);       // bring virtual charger sub-steps up to the return instant
         __syncthreads();
+        return suspended;
     }
 };
 
@@ -1655,7 +1662,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
 
 template <int NPL>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
-                                                       const double* __restrict__ action, int auto_reset,
+                                                       const double* __restrict__ action, int auto_reset, int budget,
                                                        const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
     extern __shared__ double smem[];
     const int env = blockIdx.x;
@@ -1663,11 +1670,12 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     if (env >= dp->B) return;
     bool do_reset = reset_call != 0;
     if (reset_call && env_mask && env_mask[env] == 0) return;
-    int aid = -1;
+    int aid = -1, resume = 0;
     if (!reset_call) {
         aid = agent_id[env];
         if (aid == -2) return;
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
+        resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
     }
     Sim<NPL> s;
     s.bind(dp, env, lane, smem);
@@ -1677,7 +1685,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
 #endif
     const WrsnEnvConst* ec = s.EC();
     s.load(do_reset ? dp->snap : dp->live);
-    int terminal = 0;
+    int terminal = 0, susp = 0;
     if (do_reset) {
         const double* rs = dp->snap.ring + (size_t)env * WRSN_RING * s.NP; double* rl = dp->live.ring + (size_t)env * WRSN_RING * s.NP;
         for (int w = lane; w < WRSN_RING * s.NP; w += 64) rl[w] = rs[w];
@@ -1693,7 +1701,13 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
         }
     } else {
         // ------------------------------------------------------ WRSN.step
-        if (lane == 0) {
+        if (lane == 0 && resume) {
+            const WrsnEnvDyn* dy = dp->live.dyn + env;
+            s.SS()->L = dy->cond_L;
+            for (int j = 0; j <= s.M; ++j) { s.SCA()[j] = dy->cond_agent[j]; s.SCTR()[j] = dy->cond_trig[j]; s.SCP()[j] = dy->cond_pend[j]; s.SCT()[j] = dy->cond_time[j]; s.SCS()[j] = dy->cond_seq[j]; }
+            s.SREQ()[3] = 0;
+        }
+        if (lane == 0 && !resume) {
             int st0 = 0;
             if (aid >= 0 && aid < s.M) {
                 double act[3];
@@ -1724,11 +1738,22 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
         double fit = 0.0;
         if (st0 == 2) terminal = 1;
         else {
-            s.run(false, 0.0);                               // env.run(until=general_process)
-            if (s.alive == 0) terminal = 1;                  // WRSN.py:312-320
+            susp = s.run(false, 0.0, budget) ? 1 : 0;        // env.run(until=general_process)
+            if (susp) { }
+            else if (s.alive == 0) terminal = 1;             // WRSN.py:312-320
             else { fit = s.min_fitness(); s.last_minfit = fit; }
         }
-        if (lane == 0) {
+        if (lane == 0 && susp) {                             // no request yet: status 4, the next launch goes on
+            WrsnEnvDyn* dy = dp->live.dyn + env;
+            dy->cond_L = s.SS()->L;
+            for (int j = 0; j <= s.M; ++j) { dy->cond_agent[j] = s.SCA()[j]; dy->cond_trig[j] = s.SCTR()[j]; dy->cond_pend[j] = s.SCP()[j]; dy->cond_time[j] = s.SCT()[j]; dy->cond_seq[j] = s.SCS()[j]; }
+            if (out.agent_id) out.agent_id[env] = -1;
+            if (out.reward) out.reward[env] = 0.0;
+            if (out.terminal) out.terminal[env] = 0;
+            if (out.now) out.now[env] = s.now;
+            if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
+        }
+        if (lane == 0 && !susp) {
             int agent = -1, status = st0; double reward = 0.0;
             if (!terminal) {
                 for (int m = s.M - 1; m >= 0; --m) if (s.agent_at_rest(m)) agent = m;   // lowest id (WRSN.py:321-322)
@@ -1746,7 +1771,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.status) out.status[env] = status;
         }
     }
-    s.store(dp->live, terminal, do_reset ? 0 : 1);
+    s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp);
 #ifdef WRSN_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
 #endif
@@ -1866,7 +1891,7 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
 // v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain over the nodes).  One 256-thread workgroup per environment: wave w
 // owns the 32-row band w of the (padded 128 x 128) map = 4 accumulator tiles; node chunks are expanded into LDS rows
 // A[k][i] = w_k g(x_i - x_k), B[k][j] = g(y_j - y_k).  Maps 2-4 are at most M rank-1 terms and stay on the VALU.
-#define WRSN_OBS_CH 32
+#define WRSN_OBS_CH 16
 #define WRSN_OBS_LD 128
 #ifndef WRSN_V16F_DEFINED
 typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
@@ -1882,7 +1907,7 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
     const WrsnEnvDyn* dy = d.live.dyn + env;
     double* pc = smem;                                     // [NP][3]  cx, cy, weight of every node (0 weight: dead)
     float* A = (float*)(pc + 3 * NP);                      // [CH][LD]  weight * g(x - x_n), zero beyond G
-    float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n)
+    float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n); a second (A, B) pair follows: double buffer
     const double fx0 = ec->frame[0], fy0 = ec->frame[2];
     const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
     const double unit = 1.0 / G;
@@ -1907,37 +1932,51 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
 #pragma unroll
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH) {
-        __syncthreads();                                   // pc ready / previous chunk consumed
-#ifndef WRSN_OBS_NO_FILL
-        for (int idx = tid; idx < WRSN_OBS_CH * 2 * WRSN_OBS_LD; idx += 256) {
-            const int n = idx >> 8, r = idx & 255;         // LD = 128: 256 entries (x row, y row) per node
-            const bool isx = r < WRSN_OBS_LD; const int c = r & (WRSN_OBS_LD - 1);
-            float v = 0.f;
-            if (c < G && c0 + n < N) {
-                const double cen = unit / 2 + c * unit;
-                const float df = (float)(cen - pc[(c0 + n) * 3 + (isx ? 0 : 1)]);      // difference in float64, then float32
-                v = __expf(df * df * (isx ? inv2hx : inv2hy));
-                if (isx) v *= (float)pc[(c0 + n) * 3 + 2];
-            }
-            if (isx) A[n * WRSN_OBS_LD + c] = v; else Bm[n * WRSN_OBS_LD + c] = v;
+    // Chunks of CH nodes, double-buffered: while the matrix cores work on chunk c every thread expands its column of
+    // chunk c + 1 (thread tid owns column tid & 127 of the x rows (tid < 128) or of the y rows), two nodes per k-step,
+    // so the v_exp / LDS-write work sits in the shadow of the 64-cycle MFMAs instead of in a phase of its own.
+    const bool isx = tid < WRSN_OBS_LD; const int col = tid & (WRSN_OBS_LD - 1);
+    const double cen = unit / 2 + col * unit;
+    const float kexp = (isx ? inv2hx : inv2hy) * 1.44269504f;                // exp(t) = 2^(t log2 e)
+    const int pco = isx ? 0 : 1;
+    const bool colok = col < G;
+    auto fill_one = [&](float* dstA, float* dstB, int n, int gn) {
+        float v = 0.f;
+        if (colok && gn < N) {
+            const float df = (float)(cen - pc[gn * 3 + pco]);               // difference in float64, then float32
+            v = __builtin_amdgcn_exp2f(df * df * kexp);
+            if (isx) v *= (float)pc[gn * 3 + 2];
         }
+        (isx ? dstA : dstB)[n * WRSN_OBS_LD + col] = v;
+    };
+    __syncthreads();                                       // pc ready
+#ifndef WRSN_OBS_NO_FILL
+    for (int n = 0; n < WRSN_OBS_CH; ++n) fill_one(A, Bm, n, n);
 #endif
-        __syncthreads();
+    __syncthreads();
+    int cur = 0;
+    for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH, cur ^= 1) {
+        const float* Ac = A + cur * (2 * WRSN_OBS_CH * WRSN_OBS_LD); const float* Bc = Ac + WRSN_OBS_CH * WRSN_OBS_LD;
+        float* An = A + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD); float* Bn = An + WRSN_OBS_CH * WRSN_OBS_LD;
+        const bool more = c0 + WRSN_OBS_CH < N;
+#pragma unroll
+        for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
 #ifndef WRSN_OBS_NO_MFMA
-        if (band) {
-#pragma unroll 4
-            for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
+            if (band) {
                 // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
-                const float a = A[(k2 + half) * WRSN_OBS_LD + row0 + l31];
+                const float a = Ac[(k2 + half) * WRSN_OBS_LD + row0 + l31];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float b = Bm[(k2 + half) * WRSN_OBS_LD + 32 * t + l31];
+                    const float b = Bc[(k2 + half) * WRSN_OBS_LD + 32 * t + l31];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
             }
-        }
 #endif
+#ifndef WRSN_OBS_NO_FILL
+            if (more) { fill_one(An, Bn, k2, c0 + WRSN_OBS_CH + k2); fill_one(An, Bn, k2 + 1, c0 + WRSN_OBS_CH + k2 + 1); }
+#endif
+        }
+        __syncthreads();                                   // next chunk complete, this one consumed
     }
     // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (band) {
@@ -1993,4 +2032,4 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
 #endif
 }
 
-static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return NP * 3 * 8 + WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return NP * 3 * 8 + 2 * WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }

@@ -52,15 +52,16 @@ class RolloutStats:
         self.M = int(n_agent)
         self.buf = torch.zeros((int(n_env_local), self.M + 3), dtype=torch.float64, device=device)
 
-    def update(self, agent_id, reward, terminal, now):
-        """Accumulate one batch of returns.  Pure elementwise device ops (no index kernels, no host sync)."""
+    def update(self, agent_id, reward, terminal, now, status=None):
+        """Accumulate one batch of returns.  Pure elementwise device ops (no index kernels, no host sync).
+        Rows whose step is still in flight (status 4, VecWRSN step_budget) carry no request and count no decision."""
         t = self.torch
         for m in range(self.M):
             self.buf[:, m] += reward * (agent_id == m)
         term = terminal.to(t.float64)
         self.buf[:, self.M] += term
         self.buf[:, self.M + 1] += term * now
-        self.buf[:, self.M + 2] += 1.0
+        self.buf[:, self.M + 2] += 1.0 if status is None else (status != 4).to(t.float64)
 
     def gather(self, group=None):
         """All ranks receive the [world * B_local, M + 3] table (rank-major, i.e. global environment order for

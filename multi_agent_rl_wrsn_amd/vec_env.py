@@ -27,10 +27,15 @@ class VecWRSN:
     agent_type: dict / YAML path of the charger parameters (mc_types/default.yaml), None = shipped defaults
     num_agent : number of mobile chargers per environment (`num_agent`, WRSN.py:26)
     auto_reset: an environment whose last return was terminal is reset by the next `step` (status 3)
+    step_budget: 0 = every `step` runs each WRSN.step to its end (the reference's blocking call).  > 0 bounds the work
+                of one launch per environment (simulated seconds + 32 per packet-exact second + 4 per service): an
+                environment whose step is still in flight reports status 4 / agent_id -1 and simply goes on in the
+                next `step` (its agent_id / action row is ignored).  Requests are identical either way; only the
+                launch they appear in differs, so a batch no longer waits for its slowest environment.
     """
 
     def __init__(self, scenarios, agent_type=None, num_agent=3, map_size=100, warm_up_time=100, device="cuda:0",
-                 auto_reset=False, render=True, max_degree=0, max_cover=0):
+                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("VecWRSN needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -57,6 +62,9 @@ class VecWRSN:
             self._h = _lib.RawHandle(lib, self.num_env, self.n_node, self.n_target, self.num_agent, self.map_size,
                                      self.warm_up_time, dev_index, max_degree, max_cover)
             self._h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            self.step_budget = int(step_budget)
+            if self.step_budget:
+                self._h.set_step_budget(self.step_budget)
             # topology build + warm-up + snapshot happen on the device inside set_scenario
             self._h.set_scenarios(scenarios, self.mc_spec)
             B, G = self.num_env, self.map_size
@@ -116,6 +124,10 @@ class VecWRSN:
             out = t.zeros((self.num_env, 4, self.map_size, self.map_size), dtype=t.float32, device=self.device)
         self._h.render(a.data_ptr(), out.data_ptr())
         return out
+
+    def set_step_budget(self, work_units):
+        self.step_budget = int(work_units)
+        self._h.set_step_budget(self.step_budget)
 
     def synchronize(self):
         self._h.sync()

@@ -178,6 +178,9 @@ class WRSN:
         ids = t.tensor([-1 if agent_id is None else int(agent_id)], dtype=t.int32)
         r = self.vec.step(ids, t.tensor(act3.reshape(1, 3), dtype=t.float64))
         self.vec.synchronize()
+        while int(r["status"][0]) == 4:                      # only with a step budget: the step is still in flight
+            r = self.vec.step(ids, t.tensor(act3.reshape(1, 3), dtype=t.float64))
+            self.vec.synchronize()
         self._now = float(r["now"][0])
         status = int(r["status"][0])
         if status < 0:

@@ -123,3 +123,34 @@ def test_emulated_auto_reset_and_untouched_rows(hip_lib):
             break
         ids[0] = ev.agent_id[0]
     assert seen_reset
+
+
+@pytest.mark.parametrize("name", ["hanoi1000n50_m3_s1", "hanoi1000n50_m3_cap1500_mcdeath", "six_m3_bs_charge_ongrid", "hanoi1000n100_m3_s5"])
+def test_emulated_step_budget_returns_the_same_requests(name):
+    """wrsn_set_step_budget: a WRSN.step that exceeds the work budget of a launch reports status 4 and goes on in the
+    next launch; the sequence of requests (and the state behind them) is the one of the blocking call."""
+    z = load_golden(name)
+    from multi_agent_rl_wrsn_amd.scenario import scenario_from_golden
+    sc, mc = scenario_from_golden(z)
+    ev = _emu([sc], mc, int(z["num_agent"]), map_size=int(z["map_size"]), warm_up_time=float(z["warm_up"]))
+    ev.h.set_step_budget(25)
+    ev.reset()
+    n_susp = 0
+    for k in range(len(z["in_action"])):
+        ev.step([int(z["in_agent"][k])], z["in_action"][k][None])
+        guard = 0
+        while int(ev.status[0]) == 4:
+            assert int(ev.agent_id[0]) == -1 and not bool(ev.terminal[0])
+            n_susp += 1; guard += 1
+            assert guard < 10000
+            ev.step([-1], np.zeros((1, 3)))                  # the row is ignored while the step is in flight
+        if z["is_none"][k]:
+            assert int(ev.status[0]) == 1 and int(ev.agent_id[0]) == -1
+            break
+        assert int(ev.status[0]) == 0
+        if np.isinf(z["reward"][k]):
+            continue
+        check_decision(z, k, _got(ev), where=name + " (budget)")
+        if z["terminal"][k]:
+            break
+    assert n_susp > 0

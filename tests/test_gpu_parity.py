@@ -194,6 +194,69 @@ def test_full_size_properties_4096_envs_200_nodes():
     env.close()
 
 
+def test_step_budget_gives_the_same_requests_as_blocking_steps():
+    """wrsn_set_step_budget only changes the launch a request is reported in: per environment the sequence of requests
+    (agent, simulated time, reward, terminal, observation) of a budgeted run equals the blocking run bit for bit."""
+    torch = _torch()
+    from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
+    B, K = 96, 12
+    scs = [synth_scenario(500 + e, 200, 200) for e in range(B)]
+    g = torch.Generator().manual_seed(3)
+    acts = torch.rand((K, B, 3), generator=g, dtype=torch.float64)
+
+    def blocking():
+        env = VecWRSN(scs, None, 3)
+        r = env.reset(); env.synchronize()
+        hist = [[] for _ in range(B)]
+        done = np.zeros(B, dtype=bool)
+        for k in range(K):
+            ids = r["agent_id"].clone(); ids[torch.from_numpy(done).to(ids.device)] = -2
+            r = env.step(ids, acts[k]); env.synchronize()
+            a = r["agent_id"].cpu().numpy(); now = r["now"].cpu().numpy(); rew = r["reward"].cpu().numpy(); term = r["terminal"].cpu().numpy()
+            obs = r["state"].cpu().numpy()
+            for e in range(B):
+                if not done[e]:
+                    hist[e].append((int(a[e]), float(now[e]), float(rew[e]), int(term[e]), float(obs[e].sum()) if a[e] >= 0 else 0.0))
+                    if term[e] or a[e] < 0: done[e] = True
+        env.close()
+        return hist
+
+    def budgeted(budget):
+        env = VecWRSN(scs, None, 3, step_budget=budget)
+        r = env.reset(); env.synchronize()
+        hist = [[] for _ in range(B)]
+        done = np.zeros(B, dtype=bool); nxt = np.zeros(B, dtype=int)      # next action index of every environment
+        busy = np.zeros(B, dtype=bool); n_busy = 0
+        cur = r["agent_id"].clone()
+        for it in range(100 * K):
+            if done.all(): break
+            ids = cur.clone()
+            act = torch.stack([acts[min(nxt[e], K - 1), e] for e in range(B)])
+            mask = done | ((nxt >= K) & ~busy)
+            ids[torch.from_numpy(mask).to(ids.device)] = -2
+            r = env.step(ids, act); env.synchronize()
+            st = r["status"].cpu().numpy(); a = r["agent_id"].cpu().numpy(); now = r["now"].cpu().numpy(); rew = r["reward"].cpu().numpy()
+            term = r["terminal"].cpu().numpy(); obs = r["state"].cpu().numpy()
+            for e in range(B):
+                if mask[e]: continue
+                if st[e] == 4:
+                    if not busy[e]: nxt[e] += 1
+                    busy[e] = True; n_busy += 1
+                    continue
+                if not busy[e]: nxt[e] += 1
+                busy[e] = False
+                hist[e].append((int(a[e]), float(now[e]), float(rew[e]), int(term[e]), float(obs[e].sum()) if a[e] >= 0 else 0.0))
+                if term[e] or a[e] < 0 or nxt[e] >= K: done[e] = True
+            cur = r["agent_id"].clone()
+        env.close()
+        assert n_busy > 0
+        return hist
+
+    h0 = blocking(); h1 = budgeted(120)
+    for e in range(B):
+        assert h0[e][:len(h1[e])] == h1[e] and len(h1[e]) == len(h0[e]), "environment %d" % e
+
+
 def test_auto_reset_on_device():
     torch = _torch()
     from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
