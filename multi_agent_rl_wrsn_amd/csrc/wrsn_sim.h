@@ -1884,6 +1884,8 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     }
 }
 
+struct WrsnTrue { static constexpr bool value = true; };
+struct WrsnFalse { static constexpr bool value = false; };
 #define WRSN_OBS_MAXROWS 16
 // ------------------------------------------------------------------ observation kernel: WRSN.get_state (WRSN.py:130-186)
 // map_1[i][j] = sum over alive nodes of w_n g(x_i - x_n; hX) g(y_j - y_n; hY) is a rank-N sum of separable Gaussians,
@@ -1896,7 +1898,7 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
 #ifndef WRSN_V16F_DEFINED
 typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
 #endif
-__global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
+__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
     extern __shared__ double smem[];
     const int env = blockIdx.x, tid = threadIdx.x;
     const int aid = agent_id[env];
@@ -1905,8 +1907,9 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
     const int N = ec->n_node, NP = d.NP, G = d.G, M = d.M;
     const size_t nb = (size_t)env * NP;
     const WrsnEnvDyn* dy = d.live.dyn + env;
-    double* pc = smem;                                     // [NP][3]  cx, cy, weight of every node (0 weight: dead)
-    float* A = (float*)(pc + 3 * NP);                      // [CH][LD]  weight * g(x - x_n), zero beyond G
+    double* pc = smem;                                     // [NP + 2 CH][2]  cx, cy of every node
+    float* wf = (float*)(pc + 2 * (NP + 2 * WRSN_OBS_CH)); // [NP + 2 CH] weight as float32 (0: dead / padding)
+    float* A = wf + NP + 2 * WRSN_OBS_CH;                  // [CH][LD]  weight * g(x - x_n)
     float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n); a second (A, B) pair follows: double buffer
     const double fx0 = ec->frame[0], fy0 = ec->frame[2];
     const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
@@ -1914,7 +1917,8 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
     const double hX = ec->charging_range / W, hY = ec->charging_range / H;
     const float inv2hx = (float)(-1.0 / (2.0 * hX * hX)), inv2hy = (float)(-1.0 / (2.0 * hY * hY));
     float* out = obs + (size_t)env * 4 * G * G;
-    const int wave = tid >> 6, l = tid & 63, half = l >> 5, l31 = l & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: `band` / `isx` become scalar branches
+    const int l = tid & 63, half = l >> 5, l31 = l & 31;
     const int row0 = 32 * wave;                            // this wave's band of map rows
     const bool band = row0 < G;
     {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
@@ -1925,57 +1929,74 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
                 cx = (d.node_x[nb + n] - fx0) / W; cy = (d.node_y[nb + n] - fy0) / H;
                 w = (d.live.CS[nb + n] / a_b2) / ((d.live.E[nb + n] - thr) / span);
             }
-            pc[n * 3 + 0] = cx; pc[n * 3 + 1] = cy; pc[n * 3 + 2] = w;
+            pc[n * 2 + 0] = cx; pc[n * 2 + 1] = cy; wf[n] = (float)w;
         }
+        for (int n = NP + tid; n < NP + 2 * WRSN_OBS_CH; n += 256) { wf[n] = 0.f; pc[n * 2 + 0] = 0.0; pc[n * 2 + 1] = 0.0; }   // the expansion runs one chunk ahead
     }
     wrsn_v16f acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // Chunks of CH nodes, double-buffered: while the matrix cores work on chunk c every thread expands its column of
-    // chunk c + 1 (thread tid owns column tid & 127 of the x rows (tid < 128) or of the y rows), two nodes per k-step,
-    // so the v_exp / LDS-write work sits in the shadow of the 64-cycle MFMAs instead of in a phase of its own.
-    const bool isx = tid < WRSN_OBS_LD; const int col = tid & (WRSN_OBS_LD - 1);
+    // chunk c + 1 (thread tid owns column tid & 127 of the x rows (tid < 128) or of the y rows), one node after every
+    // second MFMA, so the v_exp / LDS-write work sits in the shadow of the 64-cycle MFMAs instead of in a phase of its
+    // own.  The expansion is branch-free: nodes beyond N carry weight 0 (their y row is multiplied by a zero x row) and
+    // columns / rows beyond G are never stored, so neither needs a test.
+    const bool isx = wave < 2; const int col = tid & (WRSN_OBS_LD - 1);
     const double cen = unit / 2 + col * unit;
     const float kexp = (isx ? inv2hx : inv2hy) * 1.44269504f;                // exp(t) = 2^(t log2 e)
-    const int pco = isx ? 0 : 1;
-    const bool colok = col < G;
-    auto fill_one = [&](float* dstA, float* dstB, int n, int gn) {
-        float v = 0.f;
-        if (colok && gn < N) {
-            const float df = (float)(cen - pc[gn * 3 + pco]);               // difference in float64, then float32
-            v = __builtin_amdgcn_exp2f(df * df * kexp);
-            if (isx) v *= (float)pc[gn * 3 + 2];
-        }
-        (isx ? dstA : dstB)[n * WRSN_OBS_LD + col] = v;
+    const double* pcc = pc + (isx ? 0 : 1);
+    float* mine = (isx ? A : Bm) + col;                                       // column of this thread in buffer 0
+    auto expand = [&](double p, float w) {
+        const float df = (float)(cen - p);                                   // difference in float64, then float32
+        return __builtin_amdgcn_exp2f(df * df * kexp) * w;
     };
-    __syncthreads();                                       // pc ready
+    __syncthreads();                                       // pc / wf ready
 #ifndef WRSN_OBS_NO_FILL
-    for (int n = 0; n < WRSN_OBS_CH; ++n) fill_one(A, Bm, n, n);
+    for (int n = 0; n < WRSN_OBS_CH; ++n) mine[n * WRSN_OBS_LD] = expand(pcc[n * 2], isx ? wf[n] : 1.f);
 #endif
     __syncthreads();
+    // one chunk: 2 MFMAs, one expanded element, 2 MFMAs, one expanded element per k-step; the MFMA operands of the next
+    // k-step are fetched from LDS before the current MFMAs are issued, so no MFMA waits for an LDS round trip
+    auto chunk = [&](auto with_mfma, const float* Ac, const float* Bc, float* nxt, const double* pn, const float* wn) {
+        constexpr bool MF = decltype(with_mfma)::value;
+        float a_n = 0.f, b_n[4] = {0.f, 0.f, 0.f, 0.f};
+        if (MF) {
+            a_n = Ac[half * WRSN_OBS_LD + row0 + l31];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b_n[t] = Bc[half * WRSN_OBS_LD + 32 * t + l31];
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
+            const double p0 = pn[k2 * 2], p1 = pn[k2 * 2 + 2];
+            const float w0r = wn[k2], w1r = wn[k2 + 1];
+            const float w0 = isx ? w0r : 1.f, w1 = isx ? w1r : 1.f;
+            // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
+            const float a = a_n; const float b0 = b_n[0], b1 = b_n[1], b2 = b_n[2], b3 = b_n[3];
+            if (MF && k2 + 2 < WRSN_OBS_CH) {
+                a_n = Ac[(k2 + 2 + half) * WRSN_OBS_LD + row0 + l31];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b_n[t] = Bc[(k2 + 2 + half) * WRSN_OBS_LD + 32 * t + l31];
+            }
+            if (MF) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0); }
+#ifndef WRSN_OBS_NO_FILL
+            nxt[k2 * WRSN_OBS_LD] = expand(p0, w0);
+#endif
+            if (MF) { acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0); acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0); }
+#ifndef WRSN_OBS_NO_FILL
+            nxt[(k2 + 1) * WRSN_OBS_LD] = expand(p1, w1);
+#endif
+        }
+    };
     int cur = 0;
     for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH, cur ^= 1) {
         const float* Ac = A + cur * (2 * WRSN_OBS_CH * WRSN_OBS_LD); const float* Bc = Ac + WRSN_OBS_CH * WRSN_OBS_LD;
-        float* An = A + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD); float* Bn = An + WRSN_OBS_CH * WRSN_OBS_LD;
-        const bool more = c0 + WRSN_OBS_CH < N;
-#pragma unroll
-        for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
+        float* nxt = mine + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD);
+        const double* pn = pcc + (c0 + WRSN_OBS_CH) * 2; const float* wn = wf + c0 + WRSN_OBS_CH;
 #ifndef WRSN_OBS_NO_MFMA
-            if (band) {
-                // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
-                const float a = Ac[(k2 + half) * WRSN_OBS_LD + row0 + l31];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float b = Bc[(k2 + half) * WRSN_OBS_LD + 32 * t + l31];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
-            }
+        if (band) chunk(WrsnTrue(), Ac, Bc, nxt, pn, wn); else
 #endif
-#ifndef WRSN_OBS_NO_FILL
-            if (more) { fill_one(An, Bn, k2, c0 + WRSN_OBS_CH + k2); fill_one(An, Bn, k2 + 1, c0 + WRSN_OBS_CH + k2 + 1); }
-#endif
-        }
+        chunk(WrsnFalse(), Ac, Bc, nxt, pn, wn);
         __syncthreads();                                   // next chunk complete, this one consumed
     }
     // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -2032,4 +2053,4 @@ __global__ void __launch_bounds__(256) wrsn_obs_kernel(WrsnDev d, const int32_t*
 #endif
 }
 
-static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return NP * 3 * 8 + 2 * WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * (2 * 8 + 4) + 2 * WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }
