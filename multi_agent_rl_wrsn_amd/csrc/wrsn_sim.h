@@ -1893,12 +1893,12 @@ struct WrsnFalse { static constexpr bool value = false; };
 // v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain over the nodes).  One 256-thread workgroup per environment: wave w
 // owns the 32-row band w of the (padded 128 x 128) map = 4 accumulator tiles; node chunks are expanded into LDS rows
 // A[k][i] = w_k g(x_i - x_k), B[k][j] = g(y_j - y_k).  Maps 2-4 are at most M rank-1 terms and stay on the VALU.
-#define WRSN_OBS_CH 16
+#define WRSN_OBS_CH 8
 #define WRSN_OBS_LD 128
 #ifndef WRSN_V16F_DEFINED
 typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
 #endif
-__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
+__global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
     extern __shared__ double smem[];
     const int env = blockIdx.x, tid = threadIdx.x;
     const int aid = agent_id[env];
@@ -1921,6 +1921,12 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     const int l = tid & 63, half = l >> 5, l31 = l & 31;
     const int row0 = 32 * wave;                            // this wave's band of map rows
     const bool band = row0 < G;
+#ifdef WRSN_OBS_PROF
+    long long ot_[6]; ot_[0] = clock64();
+#define WRSN_OBS_STAMP(k) ot_[k] = clock64();
+#else
+#define WRSN_OBS_STAMP(k)
+#endif
     {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
         const double a_b2 = ec->alpha / (ec->beta * ec->beta), thr = ec->threshold, span = ec->capacity - ec->threshold;
         for (int n = tid; n < NP; n += 256) {
@@ -1956,6 +1962,65 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     for (int n = 0; n < WRSN_OBS_CH; ++n) mine[n * WRSN_OBS_LD] = expand(pcc[n * 2], isx ? wf[n] : 1.f);
 #endif
     __syncthreads();
+    auto maps234 = [&]() {
+    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.
+    // Term rows gx[t][G] (already scaled) and gy[t][G] go to LDS; every thread then produces elements tid, tid+256, ...
+    // Even blocks produce them before map 1, odd blocks after it: the blocks of a CU start together, and this way the
+    // store-bound phase of one half (3/4 of the observation) overlaps the matrix-core phase of the other half.  The term
+    // rows live in the second chunk buffer, which is free before the main loop starts and after it ends.
+    float* tx = A + 2 * WRSN_OBS_CH * WRSN_OBS_LD; float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
+    const WrsnAgent* ag = dy->ag;
+    for (int o = 0; o < M; ++o) {
+        int mp; double cxo, cyo, hx, hy, val;
+        if (o == aid) {
+            mp = 1;
+            cxo = (ag[o].loc[0] - fx0) / W; cyo = (ag[o].loc[1] - fy0) / H;
+            const double tmp = H < W ? H : W;
+            hx = 0.5 * tmp / W; hy = 0.5 * tmp / H;
+            val = ag[o].energy / ec->mc_capacity;
+        } else {
+            cxo = (ag[o].cur[0] - fx0) / W; cyo = (ag[o].cur[1] - fy0) / H; hx = hX; hy = hY;
+            if (ag[o].type_charging) { mp = 2; val = ag[o].cur[2] / ec->charging_time_max; }          // map_3: others not "moving"
+            else { mp = 3; val = (dist2(ag[o].loc[0], ag[o].loc[1], ag[o].cur[0], ag[aid].cur[1]) / ec->velocity) / ec->moving_time_max; }   // map_4, mixed index as in WRSN.py:184
+        }
+        for (int idx = tid; idx < 2 * G; idx += 256) {
+            const bool isx = idx < G; const int c = isx ? idx : idx - G;
+            const double cen = unit / 2 + c * unit;
+            const double df = cen - (isx ? cxo : cyo); const double h = isx ? hx : hy;
+            const float g = __expf((float)(df * df / (-2.0 * h * h)));
+            if (isx) tx[o * WRSN_OBS_LD + c] = g * (float)val; else ty[o * WRSN_OBS_LD + c] = g;
+        }
+        if (tid == 0) tmap[o] = mp;
+    }
+    __syncthreads();
+#ifndef WRSN_OBS_NO_MAPS234
+    {   // thread = column j (tid & 127), rows tid >> 7, +2, ...: the y factors of the column sit in registers, already
+        // routed to their map, and a row costs one broadcast LDS read and three FMAs per charger
+        const int j = tid & (WRSN_OBS_LD - 1);
+        float g1[WRSN_MAX_MC], g2[WRSN_MAX_MC], g3[WRSN_MAX_MC];
+#pragma unroll
+        for (int o = 0; o < WRSN_MAX_MC; ++o) {
+            const float g = (o < M) ? ty[o * WRSN_OBS_LD + j] : 0.f; const int mp = (o < M) ? tmap[o] : 0;
+            g1[o] = (mp == 1) ? g : 0.f; g2[o] = (mp == 2) ? g : 0.f; g3[o] = (mp == 3) ? g : 0.f;
+        }
+        if (j < G) {
+            float* o2 = out + (size_t)G * G + j; float* o3 = o2 + (size_t)G * G; float* o4 = o3 + (size_t)G * G;
+            for (int i = tid >> 7; i < G; i += 2) {
+                float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+                for (int o = 0; o < WRSN_MAX_MC; ++o) {
+                    if (o < M) { const float t = tx[o * WRSN_OBS_LD + i]; v1 = fmaf(t, g1[o], v1); v2 = fmaf(t, g2[o], v2); v3 = fmaf(t, g3[o], v3); }
+                }
+                o2[(size_t)i * G] = v1; o3[(size_t)i * G] = v2; o4[(size_t)i * G] = v3;
+            }
+        }
+    }
+#endif
+    };
+    WRSN_OBS_STAMP(1)
+    const bool maps_first = (blockIdx.x & 1) == 0;
+    if (maps_first) { maps234(); __syncthreads(); }
+    WRSN_OBS_STAMP(2)
     // one chunk: 2 MFMAs, one expanded element, 2 MFMAs, one expanded element per k-step; the MFMA operands of the next
     // k-step are fetched from LDS before the current MFMAs are issued, so no MFMA waits for an LDS round trip
     auto chunk = [&](auto with_mfma, const float* Ac, const float* Bc, float* nxt, const double* pn, const float* wn) {
@@ -1999,6 +2064,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
         chunk(WrsnFalse(), Ac, Bc, nxt, pn, wn);
         __syncthreads();                                   // next chunk complete, this one consumed
     }
+    WRSN_OBS_STAMP(3)
     // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (band) {
 #pragma unroll
@@ -2011,45 +2077,12 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
             }
         }
     }
-    __syncthreads();
-    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.
-    // Term rows gx[t][G] (already scaled) and gy[t][G] go to LDS; every thread then produces elements tid, tid+256, ...
-    float* tx = A; float* ty = A + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
-    const WrsnAgent* ag = dy->ag;
-    for (int o = 0; o < M; ++o) {
-        int mp; double cxo, cyo, hx, hy, val;
-        if (o == aid) {
-            mp = 1;
-            cxo = (ag[o].loc[0] - fx0) / W; cyo = (ag[o].loc[1] - fy0) / H;
-            const double tmp = H < W ? H : W;
-            hx = 0.5 * tmp / W; hy = 0.5 * tmp / H;
-            val = ag[o].energy / ec->mc_capacity;
-        } else {
-            cxo = (ag[o].cur[0] - fx0) / W; cyo = (ag[o].cur[1] - fy0) / H; hx = hX; hy = hY;
-            if (ag[o].type_charging) { mp = 2; val = ag[o].cur[2] / ec->charging_time_max; }          // map_3: others not "moving"
-            else { mp = 3; val = (dist2(ag[o].loc[0], ag[o].loc[1], ag[o].cur[0], ag[aid].cur[1]) / ec->velocity) / ec->moving_time_max; }   // map_4, mixed index as in WRSN.py:184
-        }
-        for (int idx = tid; idx < 2 * G; idx += 256) {
-            const bool isx = idx < G; const int c = isx ? idx : idx - G;
-            const double cen = unit / 2 + c * unit;
-            const double df = cen - (isx ? cxo : cyo); const double h = isx ? hx : hy;
-            const float g = __expf((float)(df * df / (-2.0 * h * h)));
-            if (isx) tx[o * WRSN_OBS_LD + c] = g * (float)val; else ty[o * WRSN_OBS_LD + c] = g;
-        }
-        if (tid == 0) tmap[o] = mp;
-    }
-    __syncthreads();
-#ifndef WRSN_OBS_NO_MAPS234
-    for (int idx = tid; idx < G * G; idx += 256) {
-        const int i = idx / G, j = idx - i * G;
-        float v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        for (int o = 0; o < M; ++o) {
-            const float p = tx[o * WRSN_OBS_LD + i] * ty[o * WRSN_OBS_LD + j];
-            const int mp = tmap[o];
-            v1 += (mp == 1) ? p : 0.f; v2 += (mp == 2) ? p : 0.f; v3 += (mp == 3) ? p : 0.f;
-        }
-        out[(size_t)G * G + idx] = v1; out[(size_t)2 * G * G + idx] = v2; out[(size_t)3 * G * G + idx] = v3;
-    }
+    WRSN_OBS_STAMP(4)
+    if (!maps_first) { __syncthreads(); maps234(); }
+#ifdef WRSN_OBS_PROF
+    ot_[5] = clock64();
+    if (tid == 0) for (int q = 0; q < 5; ++q) d.counters[(size_t)env * 24 + q] = ot_[q + 1] - ot_[q];
+    if (tid == 0) d.counters[(size_t)env * 24 + 5] = ot_[0];
 #endif
 }
 
