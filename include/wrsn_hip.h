@@ -136,10 +136,11 @@ int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t 
 /* Bound the work one wrsn_step launch spends on an environment (0, the default: every environment runs its
  * WRSN.step to the end, like the blocking call of the reference).  The duration of a WRSN.step is heavy-tailed (it
  * runs until the next charger finishes: 1 .. several thousand simulated seconds), so in a batch a launch waits for
- * its slowest environment.  With a budget (in work units: simulated seconds + 32 per packet-exact second + 4 per
- * service; deterministic, not wall-clock) an environment whose step is not finished reports status 4 / agent_id -1
+ * its slowest environment.  With a budget (in work units of roughly 400 shader cycles, counted per simulated second, grid item,
+ * service, routing rebuild and packet-exact second; deterministic, not wall-clock) an environment whose step is not finished reports status 4 / agent_id -1
  * and the next wrsn_step goes on with it, ignoring agent_id/action of that row.  Every WRSN.step is still executed
- * in full and returns exactly the same request; only the launch it is reported in changes. */
+ * in full and returns the same request (agent, time, terminal flag identical; rewards to ~1e-10, because a
+ * suspension may split a closed-form jump / a batch of the float32 priority pipeline in two); only the launch it is reported in changes. */
 int wrsn_set_step_budget(wrsn_t *h, int32_t work_units);
 
 /* Render get_state(agent) for arbitrary agents (DEVICE int32 [B], < 0 = skip) into obs (DEVICE). */

@@ -215,6 +215,7 @@ struct Sim {
     double now; int64_t seq;
     double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;   // pending grid items
     int net_phase, net_active, node_phase, frozen, deaths_flag;
+    int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
     double last_minfit;
     WRSN_PROF_DECL
 
@@ -476,7 +477,7 @@ struct Sim {
             if (!acti) bad = true;
         }
         alive = wv_any(bad) ? 0 : 1;
-        levels_dirty = 0;
+        levels_dirty = 0; work += 100;
         WRSN_PROF_ADD(6)
     }
 
@@ -525,7 +526,7 @@ struct Sim {
         }
         __syncthreads();
         opmax = wv_max(opm);
-        cache_dirty = 0; irreg = WRSN_RING; safe_ticks = 0;
+        cache_dirty = 0; irreg = WRSN_RING; safe_ticks = 0; work += 80;
         WRSN_PROF_ADD(5)
     }
 
@@ -694,7 +695,7 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) LOGBUF()[j * 64 + lane] = e_start[j] + gain[j] - E[j];
         if (any_death) { cache_dirty = 1; levels_dirty = 1; deaths_flag = 1; }
-        irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++;
+        irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++; work += 500;
         (void)any_rr;
         __syncthreads();
         WRSN_PROF_ADD(4)
@@ -1083,6 +1084,7 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) rrh[j] = any_rr ? SRR()[j * 64 + lane] * 0.5 : 0.0;
         for (long guard = 0; guard < 4000000L; ++guard) {
             if (frozen) break;
+            if (budget > 0 && work >= budget && guard > 0) break;   // out of budget: the next launch asks for this service again
             int k = 1; double bt = ur_time; int64_t bs = ur_seq;
             if (node_time < bt || (node_time == bt && node_seq < bs)) { k = 2; bt = node_time; bs = node_seq; }
             if (net_active && (net_time < bt || (net_time == bt && net_seq < bs))) { k = 0; bt = net_time; bs = net_seq; }
@@ -1097,14 +1099,15 @@ struct Sim {
                 double jf = floor(fmin(t_limit, kk + 1.0e6) - kk);
                 if (kk + jf >= t_limit) jf -= 1.0;
                 if (net_active) { double jm = floor(fmin(max_time, kk + 1.0e6) - kk); if (kk + jm >= max_time) jm -= 1.0; jf = fmin(jf, jm); }
-                const int j = (int)fmin(jf, (double)safe_ticks);
+                int j = (int)fmin(jf, (double)safe_ticks);
+                if (budget > 0 && j > budget - work) j = (budget - work > 1) ? budget - work : 1;
                 if (j >= 1) {
                     if (!any_rr && !ur_flag) {
                         // nothing but the constant per-second drain: closed form
                         const double dj = (double)j;
 #pragma unroll
                         for (int q = 0; q < NPL; ++q) E[q] -= dj * (d1[q] + d2[q]);
-                        WRSN_PROF_CNT(14, j)
+                        WRSN_PROF_CNT(14, j) work += 1;
                     } else { fused = true; nrep = j; do_ur = ur_flag; WRSN_PROF_CNT(13, j) }
                     const double ke = kk + (double)j;
                     ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
@@ -1116,7 +1119,7 @@ struct Sim {
             }
             if (!fused) {
                 // ---- one item (every O(N) routine has exactly one call site: the kernel has to fit the instruction cache)
-                WRSN_PROF_CNT(15, 1)
+                WRSN_PROF_CNT(15, 1) work += 8;
                 now = bt;
                 if (k == 0) {
                     if (net_phase == 0) {                    // Network.py:75-78
@@ -1142,9 +1145,10 @@ struct Sim {
                 while (nrep - q0 >= 8) {                     // batches of up to 64 seconds, one lane per second
                     const int nb = (nrep - q0 < 64) ? (nrep - q0) : 64;
                     if (!steady_batch(nb, rrh, any_rr)) break;
-                    q0 += nb;
+                    q0 += nb; work += nb;
                 }
             }
+            work += 4 * (nrep - q0);
             for (int q = q0; q < nrep; ++q) {
                 if (fused) {
                     if (any_rr) {
@@ -1553,12 +1557,15 @@ struct Sim {
     }
 
     // drive the environment until the run stops: lane 0 fires charger events, the wave runs the grid and the O(N) services
-    // `budget` > 0 bounds the work of one launch: ticks simulated + 32 per exact second + 4 per service.  When it is
-    // used up the run is suspended in front of the next grid service (returns true) and the following launch goes on
-    // from the stored state: lane 0 simply takes the same decision again (it has no side effect that is not idempotent).
-    WDEV bool run(bool use_limit, double limit, int budget = 0) {
+    // `budget` > 0 bounds the work of one launch in units of roughly 400 cycles: 1 per second of the time-parallel steady
+    // batch, 4 per second of the per-second steady path, 8 per generic grid item, 16 per service, 80 / 100 / 500 per
+    // routing-cache rebuild / level BFS / packet-exact second.  The grid service stops at an item boundary when the
+    // budget is used up, the run is suspended in front of the next grid service (returns true) and the following
+    // launch goes on from the stored state: lane 0 simply takes the same decision again (none of its side effects is
+    // not idempotent).  Deterministic: the launch a request appears in does not depend on timing.
+    WDEV bool run(bool use_limit, double limit, int budget_ = 0) {
         double svc = 0.0;
-        const int64_t ticks0 = n_ticks, exact0 = n_exact;
+        work = 0; budget = budget_;
         bool suspended = false;
         for (long guard = 0; guard < 8000000L; ++guard) {
             { WRSN_PROF_T0
@@ -1572,7 +1579,8 @@ struct Sim {
             const int req = SREQ()[0], arg = SREQ()[1];
             now = SREQD()[1]; seq = ((const int64_t*)SREQD())[2];      // lane 0 advanced them while firing events
             if (req == REQ_STOP) break;
-            if (budget > 0 && req == REQ_GRID && (n_ticks - ticks0) + 32 * (n_exact - exact0) + 4 * guard >= (int64_t)budget) { suspended = true; break; }
+            work += 16;
+            if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
             case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], arg != 0, SREQ()[3] != 0); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { WRSN_PROF_T0 svc = precheck(arg); WRSN_PROF_ADD(8) } break;

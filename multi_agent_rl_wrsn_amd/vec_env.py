@@ -28,7 +28,7 @@ class VecWRSN:
     num_agent : number of mobile chargers per environment (`num_agent`, WRSN.py:26)
     auto_reset: an environment whose last return was terminal is reset by the next `step` (status 3)
     step_budget: 0 = every `step` runs each WRSN.step to its end (the reference's blocking call).  > 0 bounds the work
-                of one launch per environment (simulated seconds + 32 per packet-exact second + 4 per service): an
+                of one launch per environment (units of ~400 cycles counted per simulated second / service / exact second): an
                 environment whose step is still in flight reports status 4 / agent_id -1 and simply goes on in the
                 next `step` (its agent_id / action row is ignored).  Requests are identical either way; only the
                 launch they appear in differs, so a batch no longer waits for its slowest environment.

@@ -9,7 +9,7 @@ from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 from diag_phases import NAMES, prof  # noqa
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 scs = [synth_scenario(e, 200, 200) for e in range(B)]
-env = VecWRSN(scs, None, 3, auto_reset=True, render=False)
+env = VecWRSN(scs, None, 3, auto_reset=True, render=False, step_budget=int(os.environ.get("WRSN_BUDGET", "0")))
 g = torch.Generator(device="cuda").manual_seed(1)
 r = env.reset()
 for k in range(20):
