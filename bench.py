@@ -4,8 +4,12 @@
 
 Workload (BASELINE.json configs[1]): 4096 independent environments per GPU x 200 nodes x 200 targets x 3 mobile
 chargers, seeded synthetic networks, random policy actions ~U[0,1)^3, auto-reset on terminal.
-A "step" is one VecWRSN.step over the whole batch = one WRSN.step() per environment (plus its 4x100x100
-observation); environments that were terminal are reset instead and are NOT counted as env-steps.
+A "step" is one VecWRSN.step launch over the whole batch.  With the default step budget an environment whose WRSN.step
+is not finished when its share of the launch is used up reports "still running" and goes on in the next launch (the
+duration of a WRSN.step is heavy-tailed; see include/wrsn_hip.h, wrsn_set_step_budget): `value` counts COMPLETED
+WRSN.step() calls only (each with its 4x100x100 observation) -- auto-resets and unfinished steps are not counted.
+The same workload with blocking steps (budget 0, every launch waits for its slowest environment) is measured too and
+reported under "blocking".
 Environments are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is
 one all-gather of the rollout returns table after the timed region.
 """
@@ -58,55 +62,23 @@ def cpu_baseline(scenarios, M, seconds, threads):
     return sum(counts) / dt, sum(counts), dt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
-    ap.add_argument("--nodes", type=int, default=200)
-    ap.add_argument("--targets", type=int, default=200)
-    ap.add_argument("--mcs", type=int, default=3)
-    ap.add_argument("--map-size", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--kernel-steps", type=int, default=20, help="steps of the per-kernel timing pass")
-    ap.add_argument("--step-budget", type=int, default=0,
-                    help="work units one launch may spend per environment (VecWRSN step_budget); 0 = blocking steps")
-    args = ap.parse_args()
-
-    import torch
-    from multi_agent_rl_wrsn_amd import RolloutStats, VecWRSN, init_distributed, synth_scenario
-    rank, world, local_rank = init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dist = torch.distributed if world > 1 else None
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    B, N, T, M, G = args.envs, args.nodes, args.targets, args.mcs, args.map_size
-    t_gen = time.time()
-    env0 = rank * B                                            # global environment ids of this shard
-    scenarios = [synth_scenario(args.seed + env0 + e, N, T) for e in range(B)]
-    t_gen = time.time() - t_gen
+def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup, kernel_steps):
+    """One timed run of `steps` VecWRSN.step launches on this rank's shard; returns the local numbers."""
+    from multi_agent_rl_wrsn_amd import RolloutStats, VecWRSN
+    B = len(scenarios)
     t_set = time.time()
-    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=args.step_budget)
+    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget)
     env.synchronize()
     t_set = time.time() - t_set
     stats = RolloutStats(B, M, dev)
-    gen = torch.Generator(device=dev).manual_seed(args.seed * 7919 + rank)
+    gen = torch.Generator(device=dev).manual_seed(seed * 7919 + rank)
 
     def policy():
         return torch.rand((B, 3), generator=gen, device=dev, dtype=torch.float64)
 
     r = env.reset()
-
-    def one_step():
-        nonlocal r
+    for _ in range(max(1, warmup)):                            # untimed: also loads every torch kernel the timed loop uses
         r = env.step(r["agent_id"], policy())
-
-    for _ in range(max(1, args.warmup)):                       # untimed: also loads every torch kernel the timed loop uses
-        one_step()
         stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
     stats.buf.zero_()
     torch.cuda.synchronize(dev)
@@ -115,27 +87,22 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    for _ in range(steps):
+        r = env.step(r["agent_id"], policy())
         stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     c1 = env.counters()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([c1["env_steps"] - c0["env_steps"], c1["ticks"], c1["exact_ticks"]], dtype=torch.float64, device=dev)
-    if dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    table = stats.gather()                                     # the path's one exchange step (RCCL all-gather)
-    elapsed = float(el[0]); env_steps = float(cnt[0])
+    res = {"elapsed": elapsed, "env_steps": c1["env_steps"] - c0["env_steps"], "ticks": c1["ticks"], "exact_ticks": c1["exact_ticks"],
+           "table": stats.gather(), "t_set": t_set}          # gather: the path's one exchange step (RCCL all-gather)
 
     # ---- per-kernel timing pass (HIP events on the stream the kernels are launched on) ----------------------
     stream = torch.cuda.current_stream(dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t_env = t_obs = 0.0
-    ks = max(1, args.kernel_steps)
+    ks = max(1, kernel_steps)
     steps_before = env.counters()["env_steps"]
     for _ in range(ks):
         a = policy()
@@ -149,11 +116,69 @@ def main():
         torch.cuda.synchronize(dev)
         t_env += ev[0].elapsed_time(ev[1]) * 1e-3
         t_obs += ev[1].elapsed_time(ev[2]) * 1e-3
-    steps_k = env.counters()["env_steps"] - steps_before
-    info_ticks = env.env_info()["n_ticks"]                      # simulated seconds of the running episodes
+    res["units"] = (env.counters()["env_steps"] - steps_before) / ks    # env-steps one launch completes (auto-resets excluded)
+    res["env_launch"] = t_env / ks; res["obs_launch"] = t_obs / ks
+    res["mean_episode_seconds"] = float(env.env_info()["n_ticks"].mean())
+    env.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--nodes", type=int, default=200)
+    ap.add_argument("--targets", type=int, default=200)
+    ap.add_argument("--mcs", type=int, default=3)
+    ap.add_argument("--map-size", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--kernel-steps", type=int, default=20, help="steps of the per-kernel timing pass")
+    ap.add_argument("--step-budget", type=int, default=1500,
+                    help="work units one launch may spend per environment (VecWRSN step_budget); 0 = blocking steps: every "
+                         "launch waits for its slowest WRSN.step")
+    ap.add_argument("--no-blocking-run", action="store_true", help="skip the additional blocking-mode (step_budget 0) measurement")
+    args = ap.parse_args()
+
+    import torch
+    from multi_agent_rl_wrsn_amd import init_distributed, synth_scenario
+    rank, world, local_rank = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = torch.distributed if world > 1 else None
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    B, N, T, M, G = args.envs, args.nodes, args.targets, args.mcs, args.map_size
+    t_gen = time.time()
+    env0 = rank * B                                            # global environment ids of this shard
+    scenarios = [synth_scenario(args.seed + env0 + e, N, T) for e in range(B)]
+    t_gen = time.time() - t_gen
+
+    def reduced(res):
+        el = torch.tensor([res["elapsed"]], dtype=torch.float64, device=dev)
+        cnt = torch.tensor([res["env_steps"]], dtype=torch.float64, device=dev)
+        if dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)           # slowest rank
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)          # whole job
+        return float(el[0]), float(cnt[0])
+
+    main_res = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, args.step_budget, args.steps, args.warmup, args.kernel_steps)
+    elapsed, env_steps = reduced(main_res)
+    blocking = None
+    if args.step_budget > 0 and not args.no_blocking_run:
+        bsteps = max(10, args.steps // 2)
+        bres = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, 0, bsteps, max(5, args.warmup // 2), max(2, args.kernel_steps // 2))
+        bel, bcnt = reduced(bres)
+        blocking = {"value": bcnt / bel, "unit": "env-steps/s", "steps": bsteps, "ms_per_step": 1e3 * bel / bsteps,
+                    "kernels": {"wrsn_step_kernel_ms": 1e3 * bres["env_launch"], "wrsn_obs_kernel_ms": 1e3 * bres["obs_launch"],
+                                "env_steps_per_launch": bres["units"]},
+                    "note": "step_budget 0: every launch runs each WRSN.step to its end and waits for the slowest environment"}
+
     phys_b, obs_b = algorithmic_bytes(N, T, M, G)
-    env_launch = t_env / ks; obs_launch = t_obs / ks
-    units = steps_k / ks                                        # env-steps one launch processes (auto-resets excluded)
+    env_launch, obs_launch, units = main_res["env_launch"], main_res["obs_launch"], main_res["units"]
     if env_launch >= obs_launch:
         dom, dur, per_unit = "wrsn_step_kernel", env_launch, phys_b
     else:
@@ -176,14 +201,18 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 (physics) / f32 (observation)", "data": "synthetic",
             "config": {"workload": "%d envs/GPU x %d nodes x %d targets x %d MC, random policy U[0,1)^3, auto-reset, 4x%dx%d observation" % (B, N, T, M, G, G),
-                       "step_budget": args.step_budget, "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "parallelism": "env-shard x%d" % world},
-            "env_steps_timed": env_steps, "mean_episode_seconds_so_far": float(info_ticks.mean()), "mean_return_table_rows": int(table.shape[0]),
-            "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(t_set, 2)},
+                       "step_budget": args.step_budget, "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G,
+                       "parallelism": "env-shard x%d" % world},
+            "env_steps_timed": env_steps, "mean_episode_seconds_so_far": main_res["mean_episode_seconds"],
+            "mean_return_table_rows": int(main_res["table"].shape[0]),
+            "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(main_res["t_set"], 2)},
             "kernels": {"wrsn_step_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "algorithmic_bytes_per_launch": per_unit * units, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
                          "whole_step_achieved_GBps": (phys_b + obs_b) * value / 1e9, "whole_step_frac": (phys_b + obs_b) * value / 1e9 / peak},
         }
+        if blocking is not None:
+            out["blocking"] = blocking
         if args.cpu_seconds > 0 and world == 1:
             cores = os.cpu_count() or 1
             threads = max(1, min(cores, 64))
@@ -191,7 +220,6 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
                                    "sample": "%d oracle env-steps (incl. get_state) in %.1f s on %d threads, same synthetic networks and action distribution" % (n, dt, threads)}
         print(json.dumps(out), flush=True)
-    env.close()
     if dist:
         dist.destroy_process_group()
 

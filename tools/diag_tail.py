@@ -24,6 +24,7 @@ for k in range(8):
     d = p1 - p0; kd = k1 - k0
     w = np.argsort(-kd)[:3]
     print("launch %d: kernel cycles mean %.0f  p50 %.0f p90 %.0f p99 %.0f max %.0f" % (k, kd.mean(), np.percentile(kd, 50), np.percentile(kd, 90), np.percentile(kd, 99), kd.max()))
+    print("  MEAN    " + "  ".join("%s=%d" % (n, d[:, i].mean()) for i, n in enumerate(NAMES) if d[:, i].any()))
     for e in w:
         print("  env %d cycles %d  dticks %.0f dexact %.0f devents %.0f status %d" % (e, kd[e], info1["n_ticks"][e] - info0["n_ticks"][e], info1["n_exact"][e] - info0["n_exact"][e], info1["n_events"][e] - info0["n_events"][e], int(r["status"][e])))
         print("    " + "  ".join("%s=%d" % (n, d[e, i]) for i, n in enumerate(NAMES) if d[e, i]))

@@ -1,0 +1,28 @@
+"""Summarise the rocprofv3 passes of tools/profile_round.sh into profiles/<tag>_bench_kernel_stats.csv and
+profiles/<tag>_traffic.json (run on the GPU box; the outputs come back through gpurun_out/)."""
+import collections, csv, glob, json, os, shutil, sys
+out, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(out), "profiles_" + tag)
+os.makedirs(dst, exist_ok=True)
+st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+def pmc(sub, name):
+    f = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != name: continue
+        k = "wrsn_step_kernel" if "wrsn_step_kernel" in r["Kernel_Name"] else ("wrsn_obs_kernel" if "wrsn_obs_kernel" in r["Kernel_Name"] else None)
+        if k is None or int(r["Grid_Size"]) < 64 * 1024: continue          # the bench launches only (4096 environments)
+        agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+    return agg
+fe, wr = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md HBM section) of "
+               "`python3 bench.py --steps 40 --warmup 10 --cpu-seconds 0 --kernel-steps 5 --no-blocking-run` (default step budget); counters are KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
+               "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B: doubled, an upper bound for narrower accesses)", "kernels": {}}
+for k in ("wrsn_step_kernel", "wrsn_obs_kernel"):
+    if fe[k][1] and wr[k][1]:
+        f = fe[k][0] / fe[k][1]; w = wr[k][0] / wr[k][1]
+        res["kernels"][k] = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024, "dispatches": fe[k][1]}
+json.dump(res, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
+print(json.dumps(res["kernels"], indent=1))
