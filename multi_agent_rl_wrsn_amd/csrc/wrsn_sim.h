@@ -215,6 +215,7 @@ struct Sim {
     double now; int64_t seq;
     double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;   // pending grid items
     int net_phase, net_active, node_phase, frozen, deaths_flag;
+    int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
     double last_minfit;
     WRSN_PROF_DECL
@@ -360,13 +361,14 @@ struct Sim {
     // -------------------------------------------------------------- state load / store
     WDEV void load(const WrsnNodeArrays& a) { WRSN_PROF_T0
         size_t nb = (size_t)env * NP;
-        am = 0;
+        am = 0; dirty = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
-            E[j] = a.E[nb + i]; CS[j] = a.CS[nb + i]; d1[j] = a.d1[nb + i]; d2[j] = a.d2[nb + i];
-            SRR()[i] = a.RR[nb + i];
-            int ls = a.ls[nb + i]; SLS()[i] = ls; SRCV()[i] = a.rcv[nb + i];
+            const bool real = i < N;                       // the padding up to NP is never read nor written back
+            E[j] = real ? a.E[nb + i] : 0.0; CS[j] = real ? a.CS[nb + i] : 0.0; d1[j] = real ? a.d1[nb + i] : 0.0; d2[j] = real ? a.d2[nb + i] : 0.0;
+            SRR()[i] = real ? a.RR[nb + i] : 0.0;
+            int ls = real ? a.ls[nb + i] : 0; SLS()[i] = ls; SRCV()[i] = real ? a.rcv[nb + i] : -1;
             am |= (unsigned)(ls & 1) << j;
         }
         const WrsnEnvDyn* dy = a.dyn + env;
@@ -396,8 +398,12 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
-            a.E[nb + i] = E[j]; a.CS[nb + i] = CS[j]; a.d1[nb + i] = d1[j]; a.d2[nb + i] = d2[j];
-            a.RR[nb + i] = SRR()[i]; a.ls[nb + i] = SLS()[i]; a.rcv[nb + i] = SRCV()[i];
+            if (i < N) {                                   // arrays nothing touched since load() are not written back
+                a.E[nb + i] = E[j]; a.RR[nb + i] = SRR()[i];
+                if (dirty & 4) a.CS[nb + i] = CS[j];
+                if (dirty & 1) { a.d1[nb + i] = d1[j]; a.d2[nb + i] = d2[j]; a.rcv[nb + i] = SRCV()[i]; }
+                if (dirty & 2) a.ls[nb + i] = SLS()[i];
+            }
         }
         WrsnEnvDyn* dy = a.dyn + env;
         if (lane == 0) {
@@ -477,7 +483,7 @@ struct Sim {
             if (!acti) bad = true;
         }
         alive = wv_any(bad) ? 0 : 1;
-        levels_dirty = 0; work += 100;
+        levels_dirty = 0; work += 100; dirty |= 2;
         WRSN_PROF_ADD(6)
     }
 
@@ -526,7 +532,7 @@ struct Sim {
         }
         __syncthreads();
         opmax = wv_max(opm);
-        cache_dirty = 0; irreg = WRSN_RING; safe_ticks = 0; work += 80;
+        cache_dirty = 0; irreg = WRSN_RING; safe_ticks = 0; work += 80; dirty |= 1;
         WRSN_PROF_ADD(5)
     }
 
@@ -695,7 +701,7 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) LOGBUF()[j * 64 + lane] = e_start[j] + gain[j] - E[j];
         if (any_death) { cache_dirty = 1; levels_dirty = 1; deaths_flag = 1; }
-        irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++; work += 500;
+        irreg = WRSN_RING; log_pending = 1; safe_ticks = 0; n_exact++; work += 500; dirty |= 7;
         (void)any_rr;
         __syncthreads();
         WRSN_PROF_ADD(4)
@@ -755,7 +761,7 @@ struct Sim {
                 }
             }
             if (len < WRSN_RING) ring_len = len + 1; else ring_head = (head + 1) % WRSN_RING;
-            irreg--;
+            irreg--; dirty |= 4;
         }
         log_pending = 0; n_ticks++;
     }
@@ -814,7 +820,7 @@ struct Sim {
     }
 
     // -------------------------------------------------------------- time-parallel steady batch
-    // nb (<= 64) consecutive whole seconds of the steady path at once: lane s owns second s and loops over the nodes,
+    // nb (<= 64) consecutive whole seconds of the steady path at once: a lane owns one second and loops over (a part of) the nodes,
     // whose state is broadcast from LDS (one 16-byte and one 4-byte read per node, four nodes in flight).  Uncharged
     // nodes follow E0 - (s+1)(d1+d2); the few nodes under charge get their clamped recursion (Node.py:60,68) tabulated
     // per second by one lane each and are added after the main loops (they are staged as "priority 0" nodes, whose
@@ -858,13 +864,20 @@ struct Sim {
             r[5] = e;
         }
         __syncthreads();
-        const bool on = lane < nb;
-        const int ls = on ? lane : 0;
+        // lanes = S seconds x P node partitions (S = nb rounded up to a power of two >= 8, P = 64 / S): a short batch
+        // costs proportionally less; the partial sums of a second are combined with log2(P) xor-shuffles
+        int S = 8; while (S < nb) S <<= 1;
+        const int sidx = lane & (S - 1), part = lane / S, P = 64 / S;
+        const bool on = sidx < nb && part == 0;              // the lane that owns the second's result
+        const int ls = sidx < nb ? sidx : 0;
         const double sp1 = -(double)(ls + 1);
-        const int N4 = N & ~3;
+        const int chunk = (((N + P - 1) / P) + 3) & ~3;      // nodes per partition, multiple of 4
+        const int i0 = part * chunk;
+        const int i1 = (i0 + chunk < N) ? i0 + chunk : N;    // may be <= i0 for the last partitions
+        const int i4 = (i1 > i0) ? i0 + ((i1 - i0) & ~3) : i0;
         // -- pass 1: mean / variance of the priorities of "my" second
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-        for (int i = 0; i < N4; i += 4) {
+        for (int i = i0; i < i4; i += 4) {
             const D2 p0 = sA[i], p1 = sA[i + 1], p2 = sA[i + 2], p3 = sA[i + 3];
             const F2 c01 = *(const F2*)(sC + i), c23 = *(const F2*)(sC + i + 2);
             const double x0 = (double)(c01.x * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf));
@@ -874,16 +887,19 @@ struct Sim {
             a0 += x0; a1 += x1; a2 += x2; a3 += x3;
             b0 = fma(x0, x0, b0); b1 = fma(x1, x1, b1); b2 = fma(x2, x2, b2); b3 = fma(x3, x3, b3);
         }
-        for (int i = N4; i < N; ++i) {
+        for (int i = i4; i < i1; ++i) {
             const D2 p0 = sA[i];
             const double x0 = (double)(sC[i] * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf));
             a0 += x0; b0 = fma(x0, x0, b0);
         }
-        for (int c = 0; c < nchg; ++c) {
-            const double x0 = (double)((float)rec[8 * c + 6] * __builtin_amdgcn_rcpf((float)(tab[c * 64 + ls] - thr) + epsf));
-            a1 += x0; b1 = fma(x0, x0, b1);
+        if (part == 0) {
+            for (int c = 0; c < nchg; ++c) {
+                const double x0 = (double)((float)rec[8 * c + 6] * __builtin_amdgcn_rcpf((float)(tab[c * 64 + ls] - thr) + epsf));
+                a1 += x0; b1 = fma(x0, x0, b1);
+            }
         }
-        const double s1 = (a0 + a1) + (a2 + a3), s2 = (b0 + b1) + (b2 + b3);
+        double s1 = (a0 + a1) + (a2 + a3), s2 = (b0 + b1) + (b2 + b3);
+        for (int m = S; m < 64; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
         const double mean = s1 / N;
         double var = s2 / N - mean * mean; var = var > 0.0 ? var : 0.0;
         float sd = __builtin_amdgcn_sqrtf((float)var); if (sd == 0.f) sd = epsf;
@@ -891,7 +907,7 @@ struct Sim {
         const float mk2 = -(float)mean * k2;
         // -- pass 2: normaliser
         a0 = 0.0; a1 = 0.0; a2 = 0.0; a3 = 0.0;
-        for (int i = 0; i < N4; i += 4) {
+        for (int i = i0; i < i4; i += 4) {
             const D2 p0 = sA[i], p1 = sA[i + 1], p2 = sA[i + 2], p3 = sA[i + 3];
             const F2 c01 = *(const F2*)(sC + i), c23 = *(const F2*)(sC + i + 2);
             const float x0 = c01.x * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf);
@@ -901,17 +917,21 @@ struct Sim {
             a0 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2)); a1 += (double)__builtin_amdgcn_exp2f(fmaf(x1, k2, mk2));
             a2 += (double)__builtin_amdgcn_exp2f(fmaf(x2, k2, mk2)); a3 += (double)__builtin_amdgcn_exp2f(fmaf(x3, k2, mk2));
         }
-        for (int i = N4; i < N; ++i) {
+        for (int i = i4; i < i1; ++i) {
             const D2 p0 = sA[i];
             const float x0 = sC[i] * __builtin_amdgcn_rcpf((float)fma(sp1, p0.y, p0.x) + epsf);
             a0 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2));
         }
-        const double ez = (double)__builtin_amdgcn_exp2f(fmaf(0.f, k2, mk2));   // what a "priority 0" node added above
-        for (int c = 0; c < nchg; ++c) {
-            const float x0 = (float)rec[8 * c + 6] * __builtin_amdgcn_rcpf((float)(tab[c * 64 + ls] - thr) + epsf);
-            a1 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2)) - ez;
+        if (part == 0) {
+            const double ez = (double)__builtin_amdgcn_exp2f(fmaf(0.f, k2, mk2));   // what a "priority 0" node added above
+            for (int c = 0; c < nchg; ++c) {
+                const float x0 = (float)rec[8 * c + 6] * __builtin_amdgcn_rcpf((float)(tab[c * 64 + ls] - thr) + epsf);
+                a1 += (double)__builtin_amdgcn_exp2f(fmaf(x0, k2, mk2)) - ez;
+            }
         }
-        float tot = (float)((a0 + a1) + (a2 + a3)); if (tot == 0.f) tot = epsf;
+        double es = (a0 + a1) + (a2 + a3);
+        for (int m = S; m < 64; m <<= 1) es += __shfl_xor(es, m);
+        float tot = (float)es; if (tot == 0.f) tot = epsf;
         const double scale = (double)__builtin_amdgcn_rcpf(tot) * inv_a_b2;
         // -- connected entries: contribution of every second, summed over the seconds (entries are grouped by charger)
         const int n = SURN()[0];
@@ -1665,6 +1685,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
             s.SAG()[m].prev_minfit = fit; s.SAG()[m].excl = 0.0;
         }
     }
+    s.dirty = 7;
     s.store(dp->snap, 0, 0);
 }
 
@@ -1693,6 +1714,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
 #endif
     const WrsnEnvConst* ec = s.EC();
     s.load(do_reset ? dp->snap : dp->live);
+    if (do_reset) s.dirty = 7;                             // the snapshot goes to the live arrays in full
     int terminal = 0, susp = 0;
     if (do_reset) {
         const double* rs = dp->snap.ring + (size_t)env * WRSN_RING * s.NP; double* rl = dp->live.ring + (size_t)env * WRSN_RING * s.NP;
