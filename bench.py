@@ -70,7 +70,6 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget)
     env.synchronize()
     t_set = time.time() - t_set
-    stats = RolloutStats(B, M, dev)
     gen = torch.Generator(device=dev).manual_seed(seed * 7919 + rank)
 
     def policy():
@@ -79,8 +78,7 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     r = env.reset()
     for _ in range(max(1, warmup)):                            # untimed: also loads every torch kernel the timed loop uses
         r = env.step(r["agent_id"], policy())
-        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
-    stats.buf.zero_()
+    env.rollout_table(zero_after=True)                          # returns / episode counters are accumulated by the step kernel itself
     torch.cuda.synchronize(dev)
     c0 = env.counters()
     if dist:
@@ -89,14 +87,13 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     t0 = time.perf_counter()
     for _ in range(steps):
         r = env.step(r["agent_id"], policy())
-        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
     torch.cuda.synchronize(dev)
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     c1 = env.counters()
     res = {"elapsed": elapsed, "env_steps": c1["env_steps"] - c0["env_steps"], "ticks": c1["ticks"], "exact_ticks": c1["exact_ticks"],
-           "table": stats.gather(), "t_set": t_set}          # gather: the path's one exchange step (RCCL all-gather)
+           "table": RolloutStats.gather_table(env.rollout_table()), "t_set": t_set}   # the path's one exchange step (RCCL all-gather)
 
     # ---- per-kernel timing pass (HIP events on the stream the kernels are launched on) ----------------------
     stream = torch.cuda.current_stream(dev)

@@ -143,6 +143,12 @@ int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t 
  * suspension may split a closed-form jump / a batch of the float32 priority pipeline in two); only the launch it is reported in changes. */
 int wrsn_set_step_budget(wrsn_t *h, int32_t work_units);
 
+/* Rollout table accumulated by the step kernel since create (or since the last call with zero_after != 0):
+ * dst DEVICE double [B, M + 3] = sum of rewards per charger (the returns IPPO consumes, IPPO.py:80-81), finished
+ * episodes, sum of env.now at terminal, completed WRSN.step calls.  Asynchronous on the handle's stream; this is the
+ * buffer a data-parallel trainer all-gathers (one collective per rollout, no per-step reduction kernels). */
+int wrsn_rollout_table(wrsn_t *h, double *dst, int32_t zero_after);
+
 /* Render get_state(agent) for arbitrary agents (DEVICE int32 [B], < 0 = skip) into obs (DEVICE). */
 int wrsn_render(wrsn_t *h, const int32_t *agent_id, float *obs);
 

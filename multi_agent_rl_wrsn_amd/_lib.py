@@ -24,7 +24,7 @@ ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max"
 
 # every entry point include/wrsn_hip.h declares
 EXPORTS = ("wrsn_create", "wrsn_destroy", "wrsn_set_stream", "wrsn_set_scenario", "wrsn_reset", "wrsn_step",
-           "wrsn_set_step_budget", "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
+           "wrsn_set_step_budget", "wrsn_rollout_table", "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
            "wrsn_last_error",
            "wrsn_version")
 
@@ -74,6 +74,8 @@ def bind(lib):
     lib.wrsn_step.restype = C.c_int
     lib.wrsn_set_step_budget.argtypes = [vp, C.c_int32]
     lib.wrsn_set_step_budget.restype = C.c_int
+    lib.wrsn_rollout_table.argtypes = [vp, vp, C.c_int32]
+    lib.wrsn_rollout_table.restype = C.c_int
     lib.wrsn_render.argtypes = [vp, vp, vp]
     lib.wrsn_render.restype = C.c_int
     lib.wrsn_peek.argtypes = [vp, C.c_int32, vp]
@@ -187,6 +189,9 @@ class RawHandle:
 
     def set_step_budget(self, work_units):
         check(self.lib, self.lib.wrsn_set_step_budget(self._h, int(work_units)))
+
+    def rollout_table(self, dst_ptr, zero_after=False):
+        check(self.lib, self.lib.wrsn_rollout_table(self._h, C.c_void_p(dst_ptr), 1 if zero_after else 0))
 
     def render(self, agent_ptr, obs_ptr):
         check(self.lib, self.lib.wrsn_render(self._h, C.c_void_p(agent_ptr), C.c_void_p(obs_ptr)))

@@ -297,6 +297,14 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     return WRSN_OK;
 }
 
+int wrsn_rollout_table(wrsn_t* h, double* dst, int32_t zero_after) {
+    if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
+    if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    hipLaunchKernelGGL(wrsn_rollout_kernel, dim3((h->dev.B + 255) / 256), dim3(256), 0, h->stream, h->dev, dst, (int)zero_after);
+    HIPCHK(hipGetLastError());
+    return WRSN_OK;
+}
+
 int wrsn_render(wrsn_t* h, const int32_t* agent_id, float* obs) {
     if (!h || !agent_id || !obs) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");

@@ -1794,6 +1794,12 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
                 } else status = 1;                           // reference falls off the end and returns None
             }
             if (s.err != 0) status = -4;
+            {   // rollout table (wrsn_rollout_table): accumulated where the request is produced, no extra launch
+                WrsnEnvDyn* dy = dp->live.dyn + env;
+                if (agent >= 0) dy->roll[agent] += reward;
+                if (terminal) { dy->roll[WRSN_MAX_MC] += 1.0; dy->roll[WRSN_MAX_MC + 1] += s.now; }
+                dy->roll[WRSN_MAX_MC + 2] += 1.0;
+            }
             if (out.agent_id) out.agent_id[env] = agent;
             if (out.reward) out.reward[env] = reward;
             if (out.terminal) out.terminal[env] = (uint8_t)terminal;
@@ -1911,6 +1917,19 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
         ec->e_recv = ec->er * ec->package_size;
         ec->d0 = sqrt(ec->efs / ec->emp);
         ec->n_edges = base; ec->n_cover = tbase; ec->error = error;
+    }
+}
+
+// rollout table [B][M + 3] (returns per charger, finished episodes, sum of lifetimes, completed steps) from the per-environment accumulators
+__global__ void __launch_bounds__(256) wrsn_rollout_kernel(WrsnDev d, double* __restrict__ dst, int zero_after) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.B) return;
+    WrsnEnvDyn* dy = d.live.dyn + e;
+    const int M = d.M;
+    for (int k = 0; k < M + 3; ++k) {
+        const int q = (k < M) ? k : WRSN_MAX_MC + (k - M);
+        dst[(size_t)e * (M + 3) + k] = dy->roll[q];
+        if (zero_after) dy->roll[q] = 0.0;
     }
 }
 

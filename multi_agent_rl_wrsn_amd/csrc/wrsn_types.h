@@ -59,6 +59,9 @@ struct WrsnEnvDyn {
     // the `|` conditions of the step in flight (WRSN.py:307-311); only meaningful while susp != 0
     double cond_time[WRSN_MAX_MC + 1]; int64_t cond_seq[WRSN_MAX_MC + 1];
     int32_t cond_agent[WRSN_MAX_MC + 1], cond_trig[WRSN_MAX_MC + 1], cond_pend[WRSN_MAX_MC + 1], cond_L;
+    // rollout accumulators since create (never reset): sum of rewards per charger, finished episodes, sum of lifetimes
+    // (env.now at terminal), completed WRSN.step calls
+    double roll[WRSN_MAX_MC + 3];
     WrsnAgent ag[WRSN_MAX_MC];
     WrsnThread th[WRSN_MAX_TH];
 };

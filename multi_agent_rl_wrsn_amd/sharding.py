@@ -64,17 +64,22 @@ class RolloutStats:
         self.buf[:, self.M + 2] += 1.0 if status is None else (status != 4).to(t.float64)
 
     def gather(self, group=None):
+        return self.gather_table(self.buf, group)
+
+    @staticmethod
+    def gather_table(buf, group=None):
         """All ranks receive the [world * B_local, M + 3] table (rank-major, i.e. global environment order for
         equal shards).  One all_gather of 8 * B_local * (M + 3) bytes per rank: latency-bound on xGMI."""
+        import torch
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-            return self.buf.clone()
+            return buf.clone()
         world = dist.get_world_size(group)
-        out = self.torch.empty((world * self.buf.shape[0], self.buf.shape[1]), dtype=self.buf.dtype, device=self.buf.device)
-        if hasattr(dist, "all_gather_into_tensor") and self.buf.is_cuda:
-            dist.all_gather_into_tensor(out, self.buf.contiguous(), group=group)
+        out = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+        if hasattr(dist, "all_gather_into_tensor") and buf.is_cuda:
+            dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
         else:
-            parts = [self.torch.empty_like(self.buf) for _ in range(world)]
-            dist.all_gather(parts, self.buf.contiguous(), group=group)
-            out = self.torch.cat(parts, dim=0)
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(parts, buf.contiguous(), group=group)
+            out = torch.cat(parts, dim=0)
         return out

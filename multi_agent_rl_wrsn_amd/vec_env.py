@@ -129,6 +129,17 @@ class VecWRSN:
         self.step_budget = int(work_units)
         self._h.set_step_budget(self.step_budget)
 
+    def rollout_table(self, zero_after=False, out=None):
+        """[B, M + 3] float64 device tensor accumulated inside the step kernel: sum of rewards per charger, finished
+        episodes, sum of lifetimes (env.now at terminal), completed WRSN.step calls -- the layout of
+        `sharding.RolloutStats` (pass it to `RolloutStats.gather_table`)."""
+        t = self.torch
+        self._bind_stream()
+        if out is None:
+            out = t.empty((self.num_env, self.num_agent + 3), dtype=t.float64, device=self.device)
+        self._h.rollout_table(out.data_ptr(), zero_after)
+        return out
+
     def synchronize(self):
         self._h.sync()
 

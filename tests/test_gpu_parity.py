@@ -272,6 +272,8 @@ def test_auto_reset_on_device():
     r = env.reset()
     g = torch.Generator().manual_seed(0)
     resets = 0
+    from multi_agent_rl_wrsn_amd import RolloutStats
+    stats = RolloutStats(64, 3, env.device)
     for k in range(40):
         r = env.step(r["agent_id"].clone(), torch.rand((64, 3), generator=g, dtype=torch.float64))
         st = r["status"].cpu().numpy()
@@ -279,9 +281,14 @@ def test_auto_reset_on_device():
         was_reset = st == 3
         resets += int(was_reset.sum())
         assert np.all(r["now"].cpu().numpy()[was_reset] == 100.0) and np.all(r["agent_id"].cpu().numpy()[was_reset] == 0)
+        stats.update(r["agent_id"], r["reward"], r["terminal"], r["now"], r["status"])
     assert resets > 0
     c = env.counters()
     assert c["env_steps"] == 64 * 40 - resets
+    # the rollout table accumulated inside the step kernel = the torch-side accumulation of the same requests
+    # (last column: the kernel counts executed WRSN.step calls, RolloutStats.update counts rows)
+    tab = env.rollout_table().cpu().numpy(); ref = stats.buf.cpu().numpy()
+    assert np.allclose(tab[:, :5], ref[:, :5], rtol=1e-12, atol=1e-300) and tab[:, 5].sum() == c["env_steps"] and tab[:, 3].sum() > 0
     env.close()
 
 
