@@ -675,16 +675,15 @@ struct Sim {
         NbRegs nbr; load_neighbors(nbr);
         int a = 0, w = 64;
         for (int guard = 0; a < N && guard < 4 * N + 64; ++guard) {
-            if (need_recv) { WRSN_PROF_MARK(t0_) margin = 2.0 * walk_receivers(nbr, es); need_recv = false; WRSN_PROF_MARK(t1_) WRSN_PROF_SPAN(16, t0_, t1_) }   // (re-)route for the live status
+            if (need_recv) { margin = 2.0 * walk_receivers(nbr, es); need_recv = false; }   // (re-)route for the live status
             const int b = (a + w < N) ? a + w : N;
-            WRSN_PROF_MARK(t2_) const bool ok_ = walk_range(a, b, nbr, es, rrh, gain, margin); WRSN_PROF_MARK(t3_) WRSN_PROF_SPAN(17, t2_, t3_) WRSN_PROF_CNT(18, 1)
-            if (ok_) {
+            if (walk_range(a, b, nbr, es, rrh, gain, margin)) {
                 a = b;
                 if ((a & 63) == 0) w = 64; else if ((a & 7) == 0 && w < 8) w = 8;   // widen again at aligned boundaries
             } else if (w > 1) {
                 w = (w == 64) ? 8 : 1;                       // somebody may starve in [a, b): look closer
             } else {
-                WRSN_PROF_MARK(t4_) const int deaths = walk_single(a, es, rrh, gain); WRSN_PROF_MARK(t5_) WRSN_PROF_SPAN(19, t4_, t5_) WRSN_PROF_CNT(20, 1)
+                const int deaths = walk_single(a, es, rrh, gain);
                 if (deaths > 0) {
                     any_death = true; need_recv = true;      // everything behind the dead node is re-routed
 #pragma unroll
@@ -1491,34 +1490,63 @@ struct Sim {
 
     // Fire charger / condition events in order until the wave has to do something: run the grid up to the next
     // event (REQ_GRID), an O(N) service (REQ_PRECHECK / REQ_CONN), or the run stops (REQ_STOP).
+    // The cached "next event" lives in registers while lane 0 runs and in the LDS Scalar block between two services.
+    struct EvCache { int valid, kind, idx, prio, uf; double time, t2; int64_t seq; int64_t fired; };
     WDEV int scalar_run(double svc, bool use_limit, double limit, int* arg, double* t_lim_out, int* flags_out) {
-        switch (SS()->pend) {                                      // finish the item that asked for the service
-        case REQ_PRECHECK: p_init_tail(SS()->pend_idx, svc); SS()->ev_valid = 0; break;
-        case REQ_CONN: mc_charge_loop(SS()->pend_idx); SS()->ev_valid = 0; break;
+        Scalar* ss = SS();
+        EvCache ev; ev.valid = ss->ev_valid; ev.kind = ss->ev_kind; ev.idx = ss->ev_idx; ev.prio = ss->ev_prio; ev.uf = ss->ev_uf;
+        ev.time = ss->ev_time; ev.t2 = ss->ev2_time; ev.seq = ss->ev_seq; ev.fired = 0;
+        const int L = ss->L; const int pend0 = ss->pend, pend_idx0 = ss->pend_idx;
+        int pend_out = 0;
+        const int r = scalar_loop(ev, L, pend0, pend_idx0, &pend_out, svc, use_limit, limit, arg, t_lim_out, flags_out);
+        ss->ev_valid = ev.valid; ss->ev_kind = ev.kind; ss->ev_idx = ev.idx; ss->ev_prio = ev.prio; ss->ev_uf = ev.uf;
+        ss->ev_time = ev.time; ss->ev2_time = ev.t2; ss->ev_seq = ev.seq; ss->n_events += ev.fired; ss->pend = pend_out;
+        return r;
+    }
+
+    WDEV int scalar_loop(EvCache& ev, const int L, const int pend0, const int pend_idx0, int* pend_out, double svc, bool use_limit, double limit,
+                         int* arg, double* t_lim_out, int* flags_out) {
+        WRSN_PROF_MARK(sr0_)
+        switch (pend0) {                                      // finish the item that asked for the service
+        case REQ_PRECHECK: p_init_tail(pend_idx0, svc); ev.valid = 0; break;
+        case REQ_CONN: mc_charge_loop(pend_idx0); ev.valid = 0; break;
         case REQ_GRID:
             if (deaths_flag) {                               // a node died: chargers connected to it re-plan on the exact path
                 for (int i = 0; i < 2 * M; ++i) if (STH()[i].ff == 2 && STH()[i].pc != PC_NONE && STH()[i].pc != PC_FINISHED && SAG()[STH()[i].agent].n_live > 0) ff_fallback(i);
-                SS()->ev_valid = 0;
+                ev.valid = 0;
             }
             break;
         default: break;
         }
-        SS()->pend = 0;
+        WRSN_PROF_MARK(sr1_) WRSN_PROF_SPAN(16, sr0_, sr1_)
         for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
-            if (!SS()->ev_valid) {                                 // charger / condition state only changes when one of them fires
+            WRSN_PROF_MARK(sc0_)
+            if (!ev.valid) {                                 // charger / condition state only changes when one of them fires
                 int kind_ = -1, idx_ = 0; double bt_ = 0.0; int bp_ = 0; int64_t bs_ = 0; double t2_ = WRSN_INF;
 #define WRSN_CONSIDER(K, I, T_, P_, S_) { const double tt_ = (T_); \
                     if (kind_ < 0 || key_less(tt_, (P_), (S_), bt_, bp_, bs_)) { if (kind_ >= 0 && bt_ < t2_) t2_ = bt_; kind_ = (K); idx_ = (I); bt_ = tt_; bp_ = (P_); bs_ = (S_); } \
                     else if (tt_ < t2_) t2_ = tt_; }
-                for (int i = 0; i < 2 * M; ++i) {
-                    int pc = STH()[i].pc;
-                    if (pc != PC_NONE && pc != PC_FINISHED) WRSN_CONSIDER(3, i, STH()[i].time, STH()[i].prio, STH()[i].seq)
+                // four candidates at a time: their fields are fetched back to back (one LDS round trip), then compared
+                const int nth = 2 * M;
+                for (int i0 = 0; i0 < nth; i0 += 4) {
+                    double tt[4]; int64_t sq[4]; int pcs[4], prs[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int i = (i0 + q < nth) ? i0 + q : nth - 1; tt[q] = STH()[i].time; sq[q] = STH()[i].seq; pcs[q] = STH()[i].pc; prs[q] = STH()[i].prio; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (i0 + q < nth && pcs[q] != PC_NONE && pcs[q] != PC_FINISHED) WRSN_CONSIDER(3, i0 + q, tt[q], prs[q], sq[q])
                 }
-                for (int j = 1; j <= SS()->L; ++j) if (SCP()[j]) WRSN_CONSIDER(4, j, SCT()[j], WRSN_NORMAL, SCS()[j])
+                for (int j0 = 1; j0 <= L; j0 += 4) {
+                    double tt[4]; int64_t sq[4]; int pd[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int j = (j0 + q <= L) ? j0 + q : L; tt[q] = SCT()[j]; sq[q] = SCS()[j]; pd[q] = SCP()[j]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (j0 + q <= L && pd[q]) WRSN_CONSIDER(4, j0 + q, tt[q], WRSN_NORMAL, sq[q])
+                }
 #undef WRSN_CONSIDER
-                SS()->ev_kind = kind_; SS()->ev_idx = idx_; SS()->ev_time = bt_; SS()->ev_prio = bp_; SS()->ev_seq = bs_; SS()->ev2_time = t2_; SS()->ev_valid = 1; SS()->ev_uf = -1;
+                ev.kind = kind_; ev.idx = idx_; ev.time = bt_; ev.prio = bp_; ev.seq = bs_; ev.t2 = t2_; ev.valid = 1; ev.uf = -1;
             }
-            const int kind = SS()->ev_kind, idx = SS()->ev_idx, bp = SS()->ev_prio; const double bt = SS()->ev_time; const int64_t bs = SS()->ev_seq;
+            WRSN_PROF_MARK(sc1_) WRSN_PROF_SPAN(17, sc0_, sc1_)
+            const int kind = ev.kind, idx = ev.idx, bp = ev.prio; const double bt = ev.time; const int64_t bs = ev.seq;
             const bool have_ev = kind >= 0;
             // next grid item (wave-uniform registers; lane 0 holds the same copy)
             bool have_grid = !frozen;
@@ -1530,45 +1558,49 @@ struct Sim {
             if (!have_ev && !have_grid) { err = -7; return REQ_STOP; }      // cannot happen while a charger process runs
             double t_lim = have_ev ? bt : WRSN_INF;
             if (use_limit && limit < t_lim) t_lim = limit;
-            if (have_grid && (gt < t_lim || (have_ev && gt == bt)) && SS()->ev_uf < 0) {
+            if (have_grid && (gt < t_lim || (have_ev && gt == bt)) && ev.uf < 0) {
                 // the reward entry list is only needed by a grid service: (re)build it lazily
-                SS()->ev_uf = ur_flags();
-                if (SS()->ev_uf & 1) ur_build(); else SURN()[0] = 0;
+                WRSN_PROF_MARK(uf0_)
+                ev.uf = ur_flags();
+                if (ev.uf & 1) ur_build(); else SURN()[0] = 0;
+                WRSN_PROF_MARK(uf1_) WRSN_PROF_SPAN(18, uf0_, uf1_)
                 WRSN_PROF_EV(21, 1) WRSN_PROF_EV(23, SURN()[0])
             }
             if (have_grid && gt < t_lim) {
-                const int uf = SS()->ev_uf;
+                const int uf = ev.uf;
                 if (uf & 2) { ff_sync_all(gt); ur_build(); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
                 else *arg = 0;
                 *t_lim_out = t_lim; *flags_out = uf & 1;
                 WRSN_PROF_EV(19, 1) WRSN_PROF_EV(20, (uf & 2) ? 1 : 0)
-                SS()->pend = REQ_GRID; return REQ_GRID;
+                *pend_out = REQ_GRID; return REQ_GRID;
             }
             if (use_limit && !(have_ev && bt < limit)) { now = limit; return REQ_STOP; }
             if (have_grid && have_ev && gt == bt && key_less(gt, WRSN_NORMAL, gs, bt, bp, bs)) {
-                const int uf = SS()->ev_uf;
+                const int uf = ev.uf;
                 if (uf & 2) { ff_sync_all(gt); ur_build(); }
                 *arg = 1; *t_lim_out = t_lim; *flags_out = uf & 1;
                 WRSN_PROF_EV(22, 1)
-                SS()->pend = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
+                *pend_out = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
             }
-            now = bt; SS()->n_events++; SS()->ev_valid = 0;
+            now = bt; ev.fired++; ev.valid = 0;
             if (kind == 3) {
+                WRSN_PROF_MARK(tf0_)
                 int r = thread_fire(idx);
-                if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; return r; }
+                WRSN_PROF_MARK(tf1_) WRSN_PROF_SPAN(19, tf0_, tf1_) WRSN_PROF_CNT(20, 1)
+                if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; *pend_out = r; return r; }
                 // the same process usually owns the next event too (its hops at one instant, or its next timeout is
                 // the earliest): no rescan when nothing else can come first
                 const int pc2 = STH()[idx].pc;
                 if (pc2 != PC_NONE && pc2 != PC_FINISHED) {
                     const double t2 = STH()[idx].time;
-                    if (t2 < SS()->ev2_time && (!have_grid || t2 < gt)) {
-                        SS()->ev_kind = 3; SS()->ev_idx = idx; SS()->ev_time = t2; SS()->ev_prio = STH()[idx].prio; SS()->ev_seq = STH()[idx].seq;
-                        SS()->ev_valid = 1; SS()->ev_uf = -1;
+                    if (t2 < ev.t2 && (!have_grid || t2 < gt)) {
+                        ev.kind = 3; ev.idx = idx; ev.time = t2; ev.prio = STH()[idx].prio; ev.seq = STH()[idx].seq;
+                        ev.valid = 1; ev.uf = -1;
                     }
                 }
             } else {
                 SCP()[idx] = 0;
-                if (idx == SS()->L) return REQ_STOP;               // StopSimulation
+                if (idx == L) return REQ_STOP;               // StopSimulation
                 cond_trigger(idx + 1);
             }
         }
