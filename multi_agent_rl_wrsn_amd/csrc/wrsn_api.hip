@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/wrsn_hip.h"
@@ -41,6 +42,8 @@ struct wrsn_handle {
     int npl;
     int scenario_set;
     int lds_env, lds_obs;
+    int slots;                 // wave slots of the device for the step kernel (CUs x 8): launch-order dependent budgets
+    int epoch;                 // launch counter of wrsn_step (parity selects the in-flight list)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     std::vector<void*> allocs;
     int32_t* d_agent_tmp;      // [B] agent ids for rendering when the caller passes no agent_id output
@@ -82,13 +85,19 @@ int alloc_node_arrays(wrsn_handle* h, WrsnNodeArrays* a) {
 
 int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agent_id, const double* action,
                int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out) {
-    dim3 grid(nenv), block(64);
     const int lds = h->lds_env;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
+    const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
+    dim3 grid(budget > 0 ? 2 * nenv : nenv), block(64);
+    int epoch = 0;
+    if (budget > 0) {                                          // the list this launch fills must start empty
+        epoch = ++h->epoch;
+        HIPCHK(hipMemsetAsync(h->dev.prio_n + ((epoch + 1) & 1), 0, sizeof(int32_t), h->stream));
+    }
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else hipLaunchKernelGGL(wrsn_step_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                            auto_reset, (mode == WRSN_MODE_STEP) ? h->step_budget : 0, mask, out)
+                            auto_reset, budget, epoch, h->slots, mask, out)
     switch (h->npl) {
     case 1: WRSN_LAUNCH(1); break;
     case 2: WRSN_LAUNCH(2); break;
@@ -148,7 +157,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(WRSN_ERR_ARG, "device ordinal out of range");
     HIPCHK(hipSetDevice(cfg->device));
     wrsn_handle* h = new wrsn_handle();
-    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0;
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1;
+    { hipDeviceProp_t pr; h->slots = (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount * 8 : 2048; }
     h->npl = npl_for(cfg->n_node);
     if (h->npl < 0) { delete h; return fail(WRSN_ERR_ARG, "n_node too large"); }
     WrsnDev& d = h->dev;
@@ -187,6 +197,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = alloc_node_arrays(h, &d.live))) break;
         if ((rc = alloc_node_arrays(h, &d.snap))) break;
         if ((rc = dalloc(h, &d.counters, B * 25))) break;
+        if ((rc = dalloc(h, &d.prio_list, 2 * B))) break;
+        if ((rc = dalloc(h, &d.prio_n, 2))) break;
         if ((rc = dalloc(h, &h->d_agent_tmp, B))) break;
         if ((rc = dalloc(h, &h->d_reset_agent, B))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
@@ -293,6 +305,10 @@ int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t 
 
 int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     if (!h || work_units < 0) return fail(WRSN_ERR_ARG, "bad step budget");
+    if ((work_units > 0) != (h->step_budget > 0)) {            // (re)entering budgeted mode: no environment is listed yet
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemset(h->dev.prio_n, 0, 2 * sizeof(int32_t)));
+    }
     h->step_budget = work_units;
     return WRSN_OK;
 }

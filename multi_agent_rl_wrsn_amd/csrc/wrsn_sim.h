@@ -1723,26 +1723,53 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
 
 template <int NPL>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
-                                                       const double* __restrict__ action, int auto_reset, int budget,
+                                                       const double* __restrict__ action, int auto_reset, int budget, int epoch, int slots,
                                                        const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
     extern __shared__ double smem[];
-    const int env = blockIdx.x;
     const int lane = threadIdx.x;
+    // With a step budget the grid is 2 B blocks: the first B take the environments whose step is in flight (the long
+    // jobs of this launch, listed by the previous one) so that they start first; block B + e takes environment e
+    // unless it is in flight or was already handled in this launch.
+    int env = blockIdx.x; bool listed = false;
+    if (budget > 0 && !reset_call) {
+        if ((int)blockIdx.x < dp->B) {
+            if ((int)blockIdx.x >= dp->prio_n[epoch & 1]) return;
+            env = dp->prio_list[(size_t)(epoch & 1) * dp->B + blockIdx.x]; listed = true;
+        } else {
+            // blocks are dispatched in index order: a block far behind the first `slots` ones starts late, and what it is
+            // allowed to spend shrinks accordingly so that the launch does not wait for late long jobs.  The mapping
+            // block -> environment rotates with the launch number, so no environment is always last.
+            const int r = blockIdx.x - dp->B;
+            env = (int)(((long long)r + (long long)epoch * 1031) % dp->B);
+            const int k = dp->prio_n[epoch & 1] + r - slots;
+            if (k > 0) { const int cut = (int)((long long)budget * k / (2 * slots)); budget = (budget - cut > budget / 4) ? budget - cut : budget / 4; }
+        }
+    }
     if (env >= dp->B) return;
     bool do_reset = reset_call != 0;
     if (reset_call && env_mask && env_mask[env] == 0) return;
     int aid = -1, resume = 0;
     if (!reset_call) {
         aid = agent_id[env];
+        resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
+        if (budget > 0) {
+            if (listed) {
+                if (!resume) return;                       // reset in the meantime: block B + env handles it
+                if (aid == -2) {                           // left untouched: stays in flight, stays listed
+                    if (lane == 0) { const int pos = atomicAdd(&dp->prio_n[(epoch + 1) & 1], 1); dp->prio_list[(size_t)((epoch + 1) & 1) * dp->B + pos] = env; }
+                    return;
+                }
+            } else if (resume || dp->live.dyn[env].epoch == epoch) return;
+        }
         if (aid == -2) return;
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
-        resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
     }
     Sim<NPL> s;
     s.bind(dp, env, lane, smem);
 #ifdef WRSN_PROFILE
     for (int q_ = 0; q_ < 24; ++q_) s.prof_[q_] = 0;
     const long long kt0_ = clock64();
+    const long long wt0_ = wall_clock64();
 #endif
     const WrsnEnvConst* ec = s.EC();
     s.load(do_reset ? dp->snap : dp->live);
@@ -1814,6 +1841,8 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = 0;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
+            const int pos = atomicAdd(&dp->prio_n[(epoch + 1) & 1], 1);      // first in line in the next launch
+            dp->prio_list[(size_t)((epoch + 1) & 1) * dp->B + pos] = env;
         }
         if (lane == 0 && !susp) {
             int agent = -1, status = st0; double reward = 0.0;
@@ -1840,8 +1869,12 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
         }
     }
     s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp);
+    if (lane == 0 && !reset_call) dp->live.dyn[env].epoch = epoch;
 #ifdef WRSN_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
+#if WRSN_PROFILE >= 3
+    if (lane == 0) { dp->counters[(size_t)env * 24 + 22] = wt0_; dp->counters[(size_t)env * 24 + 23] = wall_clock64(); }
+#endif
 #endif
 }
 
