@@ -1139,6 +1139,7 @@ struct Sim {
             if (!fused) {
                 // ---- one item (every O(N) routine has exactly one call site: the kernel has to fit the instruction cache)
                 WRSN_PROF_CNT(15, 1) work += 8;
+                WRSN_PROF_MARK(gi0_)
                 now = bt;
                 if (k == 0) {
                     if (net_phase == 0) {                    // Network.py:75-78
@@ -1156,6 +1157,7 @@ struct Sim {
                     if (node_phase == 0) { node_half(rrh, any_rr); node_phase = 1; } else { node_full(rrh, any_rr); node_phase = 0; }
                     node_time = now + 1.0 * 0.5; node_seq = seq++;
                 }
+                WRSN_PROF_MARK(gi1_) WRSN_PROF_SPAN(8, gi0_, gi1_)
             }
             // ---- the steady loop: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge (Node.py:68),
             //      repeated for every whole second taken above; a lone reward item of the generic path runs it once
@@ -1187,7 +1189,7 @@ struct Sim {
             if (fused) continue;
             if (one || deaths_flag) break;
         }
-        if (ur_flag) ur_flush();
+        { WRSN_PROF_MARK(uf0_) if (ur_flag) ur_flush(); WRSN_PROF_MARK(uf1_) WRSN_PROF_SPAN(9, uf0_, uf1_) }
     }
 
     // ============================================================== SCALAR EVENT PROCESSOR (lane 0 only)
@@ -1635,8 +1637,8 @@ struct Sim {
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
             case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], arg != 0, SREQ()[3] != 0); WRSN_PROF_ADD(1) } break;
-            case REQ_PRECHECK: { WRSN_PROF_T0 svc = precheck(arg); WRSN_PROF_ADD(8) } break;
-            case REQ_CONN: { WRSN_PROF_T0 conn_build(arg); WRSN_PROF_ADD(9) } break;
+            case REQ_PRECHECK: { svc = precheck(arg); } break;
+            case REQ_CONN: { conn_build(arg); } break;
             default: break;
             }
             __syncthreads();
