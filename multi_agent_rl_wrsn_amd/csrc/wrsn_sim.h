@@ -1744,7 +1744,11 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             const int r = blockIdx.x - dp->B;
             env = (int)(((long long)r + (long long)epoch * 1031) % dp->B);
             const int k = dp->prio_n[epoch & 1] + r - slots;
-            if (k > 0) { const int cut = (int)((long long)budget * k / (2 * slots)); budget = (budget - cut > budget / 4) ? budget - cut : budget / 4; }
+#ifndef WRSN_BUDGET_SLOPE
+#define WRSN_BUDGET_SLOPE 2
+#define WRSN_BUDGET_FLOOR 4
+#endif
+            if (k > 0) { const int cut = (int)((long long)budget * k / (WRSN_BUDGET_SLOPE * slots)); budget = (budget - cut > budget / WRSN_BUDGET_FLOOR) ? budget - cut : budget / WRSN_BUDGET_FLOOR; }
         }
     }
     if (env >= dp->B) return;

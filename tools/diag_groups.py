@@ -13,7 +13,7 @@ for G in [int(x) for x in (sys.argv[1:] or ["1", "4", "8", "16", "32"])]:
     envs, reqs = [], []
     for g in range(G):
         with torch.cuda.stream(streams[g]):
-            envs.append(VecWRSN(scs[g * per:(g + 1) * per], None, 3, auto_reset=True, render=render))
+            envs.append(VecWRSN(scs[g * per:(g + 1) * per], None, 3, auto_reset=True, render=render, step_budget=int(os.environ.get("WRSN_BUDGET", "1500"))))
             reqs.append(envs[g].reset())
     gen = torch.Generator(device="cuda").manual_seed(1)
     acts = torch.rand((W + K, B, 3), generator=gen, device="cuda", dtype=torch.float64)
