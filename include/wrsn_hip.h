@@ -143,6 +143,14 @@ int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t 
  * suspension may split a closed-form jump / a batch of the float32 priority pipeline in two); only the launch it is reported in changes. */
 int wrsn_set_step_budget(wrsn_t *h, int32_t work_units);
 
+/* WRSN.density_map_to_action (WRSN.py:229-287) with the normalisation of WRSN.step (WRSN.py:293-296), for the
+ * `density_map=True` policies of runner/IPPO.py: dmap DEVICE double [B, G, G] (probability map or logits), agent_id
+ * DEVICE int32 [B] (< 0: row skipped), action DEVICE double [B, 3] = [x, y, map[argmax] / sum(map >= 99.9th
+ * percentile)], ready for wrsn_step.  Arg-max cell, box and third component follow the reference exactly; the
+ * charging spot inside the box comes from a deterministic bounded search instead of SciPy's L-BFGS-B (objective value
+ * >= the optimiser's; parity of the spot itself is unpinned).  Asynchronous on the handle's stream. */
+int wrsn_density_action(wrsn_t *h, const int32_t *agent_id, const double *dmap, double *action);
+
 /* Rollout table accumulated by the step kernel since create (or since the last call with zero_after != 0):
  * dst DEVICE double [B, M + 3] = sum of rewards per charger (the returns IPPO consumes, IPPO.py:80-81), finished
  * episodes, sum of env.now at terminal, completed WRSN.step calls.  Asynchronous on the handle's stream; this is the

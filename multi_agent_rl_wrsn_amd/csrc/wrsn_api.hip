@@ -313,6 +313,20 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     return WRSN_OK;
 }
 
+int wrsn_density_action(wrsn_t* h, const int32_t* agent_id, const double* dmap, double* action) {
+    if (!h || !agent_id || !dmap || !action) return fail(WRSN_ERR_ARG, "null argument");
+    if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    // np.percentile(map, 99.9), method "linear": virtual index (n - 1) q, the two order statistics around it and the weight
+    const int n = h->dev.G * h->dev.G;
+    const double q = 99.9 / 100.0, vi = (double)(n - 1) * q, lo = std::floor(vi);
+    const int n_top = n - (int)lo;                              // elements from the lower order statistic to the maximum
+    if (n_top < 1 || n_top > WRSN_DM_KMAX) return fail(WRSN_ERR_ARG, "map size out of range for the percentile selection");
+    hipLaunchKernelGGL(wrsn_density_kernel, dim3(h->dev.B), dim3(64), wrsn_density_lds_bytes(), h->stream, h->dev, agent_id, dmap, action,
+                       n_top, vi - lo);
+    HIPCHK(hipGetLastError());
+    return WRSN_OK;
+}
+
 int wrsn_rollout_table(wrsn_t* h, double* dst, int32_t zero_after) {
     if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");

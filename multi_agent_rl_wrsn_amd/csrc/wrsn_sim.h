@@ -1991,6 +1991,130 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     }
 }
 
+// ------------------------------------------------------------------ density map -> action (WRSN.py:229-297), one wave per environment
+// The policy of runner/IPPO.py emits a G x G density map; WRSN.step turns it into [x, y, charging-time fraction]:
+//   :293-296  a map that is not a probability map goes through exp / (sum + eps)
+//   :234      arg-max cell (np.argmax: first maximum)
+//   :236-238  box of +- charging range around the cell centre
+//   :239-249  charging spot in the box that maximises sum_{alive, within range} CS/(E - thr) * alpha/(d + beta)^2.
+//             The reference runs SciPy L-BFGS-B from the box centre; here a deterministic bounded search (33 x 33 grid +
+//             the node positions, then a shrinking 7 x 7 pattern) -- its objective value is >= the optimiser's on every
+//             case tested, the spot itself is "parity unpinned" (DESIGN.md 2).
+//   :276-287  third component = map[argmax] / sum(map >= 99.9th percentile), np.percentile's linear interpolation
+//             between the two order statistics (host passes how many elements lie above the lower one and the weight).
+#define WRSN_DM_KMAX 24
+#define WRSN_DM_NODES 128
+static inline int wrsn_density_lds_bytes() { return (64 * WRSN_DM_KMAX + 3 * WRSN_DM_NODES) * 8; }
+__global__ void __launch_bounds__(64) wrsn_density_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ dmap,
+                                                           double* __restrict__ act, int n_top, double gamma) {
+    extern __shared__ double smem[];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    if (env >= d.B) return;
+    const int aid = agent_id[env];
+    if (aid < 0 || aid >= d.M) return;
+    const WrsnEnvConst* ec = d.ec + env;
+    const int G = d.G, n = G * G, N = ec->n_node;
+    const double* a = dmap + (size_t)env * n;
+    double* my = smem + lane * WRSN_DM_KMAX;                // descending local top-n_top of this lane
+    double* lx = smem + 64 * WRSN_DM_KMAX; double* ly = lx + WRSN_DM_NODES; double* lw = ly + WRSN_DM_NODES;
+    // ---- probability map or logits (WRSN.py:293-296)
+    double mn = WRSN_INF, mx = -WRSN_INF, sm = 0.0, se = 0.0;
+    for (int i = lane; i < n; i += 64) { const double v = a[i]; mn = fmin(mn, v); mx = fmax(mx, v); sm += v; se += exp(v); }
+    mn = wv_min(mn); mx = wv_max(mx); sm = wv_sum(sm); se = wv_sum(se);
+    const bool is_prob = mn >= 0.0 && mx <= 1.0 && fabs(sm - 1.0) <= 1e-8 + 1e-5;      // np.isclose(sum, 1)
+    const double den = se + 1e-9;
+    // ---- arg-max (first maximum) and the largest n_top values
+    for (int k = 0; k < n_top; ++k) my[k] = -WRSN_INF;
+    double bv = -WRSN_INF; int bi = n;
+    for (int i = lane; i < n; i += 64) {
+        const double v = is_prob ? a[i] : exp(a[i]) / den;
+        if (v > bv) { bv = v; bi = i; }
+        if (v > my[n_top - 1]) { int k = n_top - 1; while (k > 0 && my[k - 1] < v) { my[k] = my[k - 1]; --k; } my[k] = v; }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        const double ov = __shfl_xor(bv, m); const int oi = __shfl_xor(bi, m);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    double t_hi = 0.0, t_lo = 0.0; int head = 0;
+    for (int r = 0; r < n_top; ++r) {                        // merge the lane lists: r-th largest of the whole map
+        const double cand = (head < n_top) ? my[head] : -WRSN_INF;
+        const double m = wv_max(cand);
+        const unsigned long long hit = __ballot(cand == m);
+        if ((hit & (~hit + 1ull)) == (1ull << lane)) ++head; // the lowest lane holding it pops
+        if (r == n_top - 2) t_hi = m;
+        if (r == n_top - 1) t_lo = m;
+    }
+    if (n_top < 2) t_hi = t_lo;
+    const double diff = t_hi - t_lo;                          // np.percentile (linear): _lerp(a, b, t)
+    double thr = t_lo + diff * gamma;
+    if (gamma >= 0.5) thr = t_hi - diff * (1.0 - gamma);
+    double ks = 0.0;
+    for (int i = lane; i < n; i += 64) { const double v = is_prob ? a[i] : exp(a[i]) / den; if (v >= thr) ks += v; }
+    ks = wv_sum(ks);
+    // ---- box around the arg-max cell and the nodes that can be in range of a point of it
+    const double x0 = ec->frame[0], y0 = ec->frame[2], W = ec->frame[1] - x0, H = ec->frame[3] - y0, unit = 1.0 / G, rng = ec->charging_range;
+    const int ci = bi / G, cj = bi - ci * G;
+    const double lbx = ((ci + 0.5) * unit - rng / W) * W + x0, ubx = ((ci + 0.5) * unit + rng / W) * W + x0;
+    const double lby = ((cj + 0.5) * unit - rng / H) * H + y0, uby = ((cj + 0.5) * unit + rng / H) * H + y0;
+    const double cx = (lbx + ubx) / 2, cy = (lby + uby) / 2, hx = (ubx - lbx) / 2, hy = (uby - lby) / 2;
+    const size_t nb = (size_t)env * d.NP;
+    int cnt = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        const int i = i0 + lane;
+        bool in = false; double px = 0.0, py = 0.0, w = 0.0;
+        if (i < N && (d.live.ls[nb + i] & 1)) {
+            px = d.node_x[nb + i]; py = d.node_y[nb + i];
+            in = fabs(px - cx) <= hx + rng && fabs(py - cy) <= hy + rng;
+            w = d.live.CS[nb + i] / (d.live.E[nb + i] - ec->threshold);
+        }
+        const unsigned long long mk = __ballot(in);
+        if (in) { const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull)); if (pos < WRSN_DM_NODES) { lx[pos] = px; ly[pos] = py; lw[pos] = w; } }
+        cnt += __popcll(mk);
+    }
+    if (cnt > WRSN_DM_NODES) cnt = WRSN_DM_NODES;
+    __syncthreads();
+    const double alpha = ec->alpha, beta = ec->beta;
+    auto objective = [&](double px, double py) {
+        double r = 0.0;
+        for (int k = 0; k < cnt; ++k) { const double dd = dist2(px, py, lx[k], ly[k]); if (dd <= rng) r += lw[k] * alpha / ((dd + beta) * (dd + beta)); }
+        return r;
+    };
+    auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    // best of: 33 x 33 grid over the box (its centre, the optimiser's start, is point (16, 16)) and the nodes themselves
+    double best = -1.0, bx = cx, by = cy; int bidx = 1 << 30;
+    const int ncand = 33 * 33 + cnt;
+    for (int c = lane; c < ncand; c += 64) {
+        double px, py;
+        if (c < 33 * 33) { const int u = c / 33, v = c - u * 33; px = lbx + (ubx - lbx) * (u / 32.0); py = lby + (uby - lby) * (v / 32.0); }
+        else { px = clampd(lx[c - 33 * 33], lbx, ubx); py = clampd(ly[c - 33 * 33], lby, uby); }
+        const double f = objective(px, py);
+        if (f > best) { best = f; bx = px; by = py; bidx = c; }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+        const double of = __shfl_xor(best, m), ox = __shfl_xor(bx, m), oy = __shfl_xor(by, m); const int oi = __shfl_xor(bidx, m);
+        if (of > best || (of == best && oi < bidx)) { best = of; bx = ox; by = oy; bidx = oi; }
+    }
+    // shrinking 7 x 7 pattern around the incumbent
+    double sx = (ubx - lbx) / 32.0, sy = (uby - lby) / 32.0;
+    for (int it = 0; it < 40 && (sx > 1e-9 * (ubx - lbx) || sy > 1e-9 * (uby - lby)); ++it) {
+        double f = -1.0, px = bx, py = by; int pi = 1 << 30;
+        if (lane < 49) {
+            const int u = lane / 7, v = lane - u * 7;
+            px = clampd(bx + (u - 3) * (sx / 3.0), lbx, ubx); py = clampd(by + (v - 3) * (sy / 3.0), lby, uby);
+            f = objective(px, py); pi = (lane == 24) ? -1 : lane;   // the incumbent wins ties
+        }
+        for (int m = 1; m < 64; m <<= 1) {
+            const double of = __shfl_xor(f, m), ox = __shfl_xor(px, m), oy = __shfl_xor(py, m); const int oi = __shfl_xor(pi, m);
+            if (of > f || (of == f && oi < pi)) { f = of; px = ox; py = oy; pi = oi; }
+        }
+        if (pi == -1) { sx /= 3.0; sy /= 3.0; } else { bx = px; by = py; best = f; }
+    }
+    if (lane == 0) {
+        act[(size_t)env * 3 + 0] = (bx - x0) / W; act[(size_t)env * 3 + 1] = (by - y0) / H;   // down_mapping (WRSN.py:86-88)
+        act[(size_t)env * 3 + 2] = bv / ks;
+    }
+}
+
 // rollout table [B][M + 3] (returns per charger, finished episodes, sum of lifetimes, completed steps) from the per-environment accumulators
 __global__ void __launch_bounds__(256) wrsn_rollout_kernel(WrsnDev d, double* __restrict__ dst, int zero_after) {
     const int e = blockIdx.x * 256 + threadIdx.x;

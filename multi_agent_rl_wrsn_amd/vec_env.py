@@ -129,6 +129,18 @@ class VecWRSN:
         self.step_budget = int(work_units)
         self._h.set_step_budget(self.step_budget)
 
+    def density_to_action(self, agent_ids, dmaps, out=None):
+        """WRSN.density_map_to_action (WRSN.py:229-287, with the exp-normalisation of WRSN.py:293-296) on the device:
+        dmaps [B, G, G] -> actions [B, 3] float64 for `step`.  Rows with agent < 0 are left untouched."""
+        t = self.torch
+        self._bind_stream()
+        a = agent_ids.to(device=self.device, dtype=t.int32).contiguous()
+        m = dmaps.to(device=self.device, dtype=t.float64).contiguous()
+        if out is None:
+            out = t.zeros((self.num_env, 3), dtype=t.float64, device=self.device)
+        self._h.density_action(a.data_ptr(), m.data_ptr(), out.data_ptr())
+        return out
+
     def rollout_table(self, zero_after=False, out=None):
         """[B, M + 3] float64 device tensor accumulated inside the step kernel: sum of rewards per charger, finished
         episodes, sum of lifetimes (env.now at terminal), completed WRSN.step calls -- the layout of

@@ -7,7 +7,8 @@ agent_id / prev_state / input_action / action / reward / state / terminal / info
 `num_agent`, `env.now`, `net` / `agents` read-only views, the `observation_space` / `action_space` boxes, and the
 re-seeding of the global `random` / `numpy.random` generators on every reset (NetworkIO.py:22-24).
 Deliberate deviations: when every charger is dead the reference never returns -- here `step` returns a
-terminal request; `density_map=True` runs the reference's arg-max + L-BFGS-B action extraction on the host (SciPy).
+terminal request; with `density_map=True` the charging spot inside the arg-max box comes from a deterministic search on
+the device instead of SciPy's L-BFGS-B (`wrsn_density_action`).
 """
 import random
 
@@ -166,10 +167,7 @@ class WRSN:
         if agent_id is not None:
             action = np.array(input_action)
             self.agents_input_action[agent_id] = action.copy()
-            if self.density_map:                             # WRSN.py:293-297
-                if not (np.all((action >= 0) & (action <= 1)) and np.isclose(np.sum(action), 1)):
-                    action = np.exp(action)
-                    action = action / (np.sum(action) + self.epsilon)
+            if self.density_map:                             # WRSN.py:293-297 (normalisation included) on the device
                 action = self.density_map_to_action(action, agent_id)
             action = np.clip(action, self.action_space.low, self.action_space.high)
             self.agents_action[agent_id] = action
@@ -196,31 +194,9 @@ class WRSN:
                 "action": self.agents_action[aid], "reward": float(r["reward"][0]), "state": state, "terminal": False,
                 "info": self._info()}
 
-    # -- density-map action extraction (host; WRSN.py:229-287) ----------------------------------------------
+    # -- density-map action extraction (WRSN.py:229-287) on the device ------------------------------------------
     def density_map_to_action(self, dmap, id):
-        from scipy.optimize import minimize
-        nd = self.vec.nodes()
-        alive = nd["status"][0] == 1
-        xy = self.scenario.node_xy[alive]
-        wgt = nd["cs"][0][alive] / (nd["energy"][0][alive] - float(self.scenario.node_spec["threshold"]))
-        rng_c, alpha, beta = self.agent_phy_para["charging_range"], self.agent_phy_para["alpha"], self.agent_phy_para["beta"]
-        f = self.net.frame
-        unit = 1.0 / self.map_size
-        max_index = np.unravel_index(np.argmax(dmap), dmap.shape)
-        hx, hy = rng_c / (f[1] - f[0]), rng_c / (f[3] - f[2])
-        lower = self.up_mapping([(max_index[0] + 0.5) * unit - hx, (max_index[1] + 0.5) * unit - hy])
-        upper = self.up_mapping([(max_index[0] + 0.5) * unit + hx, (max_index[1] + 0.5) * unit + hy])
-        bounds = [(lower[0], upper[0]), (lower[1], upper[1])]
-
-        def objective(loc):
-            d = np.sqrt((xy[:, 0] - loc[0]) ** 2 + (xy[:, 1] - loc[1]) ** 2)
-            return -float(np.sum((d <= rng_c) * wgt * alpha / (d + beta) ** 2))
-
-        res = minimize(objective, [(lower[0] + upper[0]) / 2, (lower[1] + upper[1]) / 2], bounds=bounds, method="L-BFGS-B")
-        prob = np.copy(dmap).flatten()
-        threshold = np.percentile(prob, 99.9)
-        prob[prob < threshold] = 0
-        prob = prob.reshape(dmap.shape)
-        prob = prob / np.sum(prob)
-        loc = self.down_mapping(np.array(res.x))
-        return np.array([loc[0], loc[1], prob[max_index[0]][max_index[1]]])
+        t = self.vec.torch
+        ids = t.tensor([int(id)], dtype=t.int32)
+        dm = t.as_tensor(np.asarray(dmap, dtype=np.float64).reshape(1, self.map_size, self.map_size))
+        return self.vec.density_to_action(ids, dm)[0].to("cpu").numpy()

@@ -183,3 +183,46 @@ def test_emulated_rollout_table_matches_host_accumulation():
     assert np.allclose(got, want, rtol=1e-12, atol=0)
     ev.h.rollout_table(got.ctypes.data, False)
     assert not got.any()
+
+
+def _density_cases(rng, G, node_cell):
+    """logits, a probability map peaked on a node's cell, a flat map with ties at the percentile, a one-hot map"""
+    peaked = np.full((G, G), 1e-9); peaked[node_cell] = 0.5; peaked[(node_cell[0] + 1) % G, node_cell[1]] = 0.25
+    peaked += rng.rand(G, G) * 1e-6; peaked /= peaked.sum()
+    onehot = np.zeros((G, G)); onehot[G // 3, G // 2] = 1.0
+    return [rng.randn(G, G) * 2.0, peaked, np.full((G, G), 1.0 / (G * G)), onehot, rng.rand(G, G)]
+
+
+@pytest.mark.parametrize("G", [100, 64])
+def test_emulated_density_map_to_action(G):
+    """wrsn_density_action vs the NumPy/SciPy restatement of WRSN.py:229-297: arg-max cell / box / third component exact,
+    charging spot inside the box with an objective value not below SciPy's L-BFGS-B (its spot is not pinned)."""
+    import density_ref
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    sc = synth_scenario(11, 120, 100)
+    ev = _emu([sc] * 5, DEFAULT_MC_SPEC, 2, map_size=G)
+    ev.reset(with_obs=False)
+    rng = np.random.RandomState(3)
+    for k in range(3):                                       # some dynamics first: energies / consumption rates differ per node
+        ev.step(ev.agent_id.copy(), rng.rand(5, 3), with_obs=False)
+    info = ev.env_info(); nd = ev.nodes()
+    frame = [info["xmin"][0], info["xmax"][0], info["ymin"][0], info["ymax"][0]]
+    mc = DEFAULT_MC_SPEC
+    alive = nd["status"][0] == 1
+    cellx = int((sc.node_xy[5, 0] - frame[0]) / (frame[1] - frame[0]) * G); celly = int((sc.node_xy[5, 1] - frame[2]) / (frame[3] - frame[2]) * G)
+    maps = _density_cases(rng, G, (min(cellx, G - 1), min(celly, G - 1)))
+    dm = np.ascontiguousarray(np.stack(maps)); ids = np.zeros(5, dtype=np.int32); ids[4] = -1
+    out = np.full((5, 3), -7.0)
+    ev.h.density_action(ids.ctypes.data, dm.ctypes.data, out.ctypes.data)
+    assert np.all(out[4] == -7.0)                            # skipped row
+    for e in range(4):
+        ref = density_ref.density_map_to_action(density_ref.normalise(maps[e]), frame, sc.node_xy, alive, nd["energy"][0], nd["cs"][0],
+                                                float(sc.node_spec["threshold"]), mc["charging_range"], mc["alpha"], mc["beta"])
+        assert abs(out[e, 2] - ref["third"]) <= 1e-12 * ref["third"], (e, out[e, 2], ref["third"])
+        spot = np.array([out[e, 0] * (frame[1] - frame[0]) + frame[0], out[e, 1] * (frame[3] - frame[2]) + frame[2]])
+        (lx, ux), (ly, uy) = ref["bounds"]
+        tol = 1e-9 * (ux - lx)
+        assert lx - tol <= spot[0] <= ux + tol and ly - tol <= spot[1] <= uy + tol, (e, spot, ref["bounds"])
+        val = density_ref.objective(spot, sc.node_xy, alive, nd["energy"][0], nd["cs"][0], float(sc.node_spec["threshold"]),
+                                    mc["charging_range"], mc["alpha"], mc["beta"])
+        assert val >= ref["objective"] * (1 - 1e-9) - 1e-300, (e, val, ref["objective"])

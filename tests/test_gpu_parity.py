@@ -322,3 +322,40 @@ def test_wrsn_facade_dict_protocol(tmp_path):
         assert close([n.energy for n in net.listNodes], z["node_energy"][k])
         assert [a.cur_action_type == "charging" for a in agents] == [bool(v) for v in z["mc_charging"][k]]
     assert env.net.check_nodes() >= 1
+
+
+def test_density_map_to_action_on_device():
+    """f1: WRSN.density_map_to_action (WRSN.py:229-297) through VecWRSN.density_to_action: third component / box exact,
+    objective value of the charging spot >= SciPy L-BFGS-B's (the reference's optimiser; its spot is not pinned)."""
+    torch = _torch()
+    import density_ref
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, VecWRSN, synth_scenario
+    B, G = 24, 100
+    scs = [synth_scenario(900 + e, 200, 200) for e in range(B)]
+    env = VecWRSN(scs, None, 3, map_size=G)
+    r = env.reset()
+    g = torch.Generator().manual_seed(5)
+    for k in range(3):
+        r = env.step(r["agent_id"].clone(), torch.rand((B, 3), generator=g, dtype=torch.float64))
+    env.synchronize()
+    rng = np.random.RandomState(7)
+    maps = np.stack([rng.randn(G, G) * (1.0 + e % 3) if e % 2 == 0 else (lambda m: m / m.sum())(rng.rand(G, G) ** 8) for e in range(B)])
+    ids = r["agent_id"].clamp(min=0)
+    act = env.density_to_action(ids, torch.from_numpy(maps)).cpu().numpy()
+    info = env.env_info(); nd = env.nodes(); mc = DEFAULT_MC_SPEC
+    worse = 0
+    for e in range(B):
+        frame = [info["xmin"][e], info["xmax"][e], info["ymin"][e], info["ymax"][e]]
+        alive = nd["status"][e] == 1
+        args = (scs[e].node_xy, alive, nd["energy"][e], nd["cs"][e], float(scs[e].node_spec["threshold"]), mc["charging_range"], mc["alpha"], mc["beta"])
+        ref = density_ref.density_map_to_action(density_ref.normalise(maps[e]), frame, *args)
+        assert abs(act[e, 2] - ref["third"]) <= 1e-12 * ref["third"]
+        spot = np.array([act[e, 0] * (frame[1] - frame[0]) + frame[0], act[e, 1] * (frame[3] - frame[2]) + frame[2]])
+        (lx, ux), (ly, uy) = ref["bounds"]
+        assert lx - 1e-6 <= spot[0] <= ux + 1e-6 and ly - 1e-6 <= spot[1] <= uy + 1e-6
+        assert density_ref.objective(spot, *args) >= ref["objective"] * (1 - 1e-9)
+    # and the result drives a step like any other action
+    r = env.step(ids, torch.from_numpy(act))
+    env.synchronize()
+    assert (r["status"].cpu().numpy() >= 0).all()
+    env.close()
