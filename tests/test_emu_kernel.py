@@ -226,3 +226,50 @@ def test_emulated_density_map_to_action(G):
         val = density_ref.objective(spot, sc.node_xy, alive, nd["energy"][0], nd["cs"][0], float(sc.node_spec["threshold"]),
                                     mc["charging_range"], mc["alpha"], mc["beta"])
         assert val >= ref["objective"] * (1 - 1e-9) - 1e-300, (e, val, ref["objective"])
+
+
+def test_emulated_step_budget_untouched_and_reset_rows():
+    """Bookkeeping of the in-flight list (wrsn_set_step_budget): an environment left untouched (agent -2) while its step
+    is in flight stays in flight and finishes later with the blocking result; a reset of an in-flight environment drops
+    the step; other environments of the batch are not disturbed."""
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    scs = [synth_scenario(60 + e, 80, 70) for e in range(4)]
+    act = np.array([[0.3, 0.6, 0.9], [0.7, 0.2, 0.8], [0.5, 0.5, 0.7], [0.2, 0.8, 0.95]])
+
+    ref = _emu(scs, DEFAULT_MC_SPEC, 2)                      # blocking run: what every finished step must return
+    ref.reset(with_obs=False)
+    ids0 = ref.agent_id.copy()
+    ref.step(ids0, act, with_obs=False)
+    want = (ref.agent_id.copy(), ref.now.copy(), ref.reward.copy())
+
+    ev = _emu(scs, DEFAULT_MC_SPEC, 2)
+    ev.h.set_step_budget(40)
+    ev.reset(with_obs=False)
+    ev.step(ids0, act, with_obs=False)
+    assert (ev.status == 4).all()                            # budget far below one step: everybody is in flight
+    done = np.zeros(4, dtype=bool); got_agent = np.full(4, -9); got_now = np.zeros(4); got_rew = np.zeros(4)
+    # environment 1 is left untouched for a while, environment 3 is reset while in flight
+    mask = np.zeros(4, dtype=np.uint8); mask[3] = 1
+    ev.h.reset(mask.ctypes.data, **ev._ptrs(False))
+    assert ev.now[3] == 100.0 and ev.agent_id[3] == ids0[3]
+    for it in range(4000):
+        ids = np.full(4, -1, dtype=np.int32)
+        ids[done] = -2; ids[3] = -2
+        if it < 50: ids[1] = -2
+        ev.step(ids, np.zeros((4, 3)), with_obs=False)
+        for e in (0, 1, 2):
+            if ids[e] == -2 or done[e]: continue
+            if ev.status[e] != 4:
+                done[e] = True; got_agent[e] = ev.agent_id[e]; got_now[e] = ev.now[e]; got_rew[e] = ev.reward[e]
+        if done[:3].all(): break
+    assert done[:3].all()
+    assert np.array_equal(got_agent[:3], want[0][:3]) and np.array_equal(got_now[:3], want[1][:3])
+    assert np.allclose(got_rew[:3], want[2][:3], rtol=1e-7, atol=1e-12)
+    # the reset environment starts a fresh step and finishes it like the blocking run
+    ids = np.full(4, -2, dtype=np.int32); ids[3] = ids0[3]
+    ev.step(ids, act, with_obs=False)
+    for it in range(4000):
+        if ev.status[3] != 4: break
+        ids[3] = -1
+        ev.step(ids, np.zeros((4, 3)), with_obs=False)
+    assert ev.status[3] != 4 and ev.agent_id[3] == want[0][3] and ev.now[3] == want[1][3]
