@@ -1918,6 +1918,21 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
         } else { dbs[i] = 0.0; nflags[i] = 0; es_bs[i] = 0.0; }
     }
     x0 = wv_min(x0); x1 = wv_max(x1); y0 = wv_min(y0); y1 = wv_max(y1);
+    {   // Morton order of the nodes on a 16 x 16 grid of the frame (ties by id): the observation kernel walks the nodes in
+        // this order so that the eight nodes of a chunk are neighbours in the plane
+        auto morton = [&](int i) {
+            int qx = (int)((nx[i] - x0) / (x1 - x0) * 16.0), qy = (int)((ny[i] - y0) / (y1 - y0) * 16.0);
+            qx = qx < 0 ? 0 : (qx > 15 ? 15 : qx); qy = qy < 0 ? 0 : (qy > 15 ? 15 : qy);
+            int k = 0;
+            for (int b = 0; b < 4; ++b) k |= (((qx >> b) & 1) << (2 * b + 1)) | (((qy >> b) & 1) << (2 * b));
+            return k * 2048 + i;
+        };
+        int32_t* xo = d.xorder + nb;
+        for (int i = lane; i < NP; i += 64) {
+            if (i < N) { const int key = morton(i); int pos = 0; for (int k = 0; k < N; ++k) pos += (morton(k) < key) ? 1 : 0; xo[pos] = i; }
+            else xo[i] = i;
+        }
+    }
     // neighbour lists sorted by (distance, id): Node.find_receiver (Node.py:92-100) keeps the first strictly nearer
     // candidate in id order, which is the minimum of (distance, id) over the candidates
     int base = 0;
@@ -2153,7 +2168,8 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
     const WrsnEnvDyn* dy = d.live.dyn + env;
     double* pc = smem;                                     // [NP + 2 CH][2]  cx, cy of every node
     float* wf = (float*)(pc + 2 * (NP + 2 * WRSN_OBS_CH)); // [NP + 2 CH] weight as float32 (0: dead / padding)
-    float* A = wf + NP + 2 * WRSN_OBS_CH;                  // [CH][LD]  weight * g(x - x_n)
+    float* bbox = wf + NP + 2 * WRSN_OBS_CH;               // [NP / CH + 2][4] x / y range of the weighted nodes of a chunk
+    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // [CH][LD]  weight * g(x - x_n)
     float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n); a second (A, B) pair follows: double buffer
     const double fx0 = ec->frame[0], fy0 = ec->frame[2];
     const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
@@ -2175,9 +2191,10 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
         const double a_b2 = ec->alpha / (ec->beta * ec->beta), thr = ec->threshold, span = ec->capacity - ec->threshold;
         for (int n = tid; n < NP; n += 256) {
             double w = 0.0, cx = 0.0, cy = 0.0;
-            if (n < N && (d.live.ls[nb + n] & 1)) {
-                cx = (d.node_x[nb + n] - fx0) / W; cy = (d.node_y[nb + n] - fy0) / H;
-                w = (d.live.CS[nb + n] / a_b2) / ((d.live.E[nb + n] - thr) / span);
+            const int src = (n < N) ? d.xorder[nb + n] : n;  // position n of the Morton order (static, built with the topology)
+            if (n < N && (d.live.ls[nb + src] & 1)) {
+                cx = (d.node_x[nb + src] - fx0) / W; cy = (d.node_y[nb + src] - fy0) / H;
+                w = (d.live.CS[nb + src] / a_b2) / ((d.live.E[nb + src] - thr) / span);
             }
             pc[n * 2 + 0] = cx; pc[n * 2 + 1] = cy; wf[n] = (float)w;
         }
@@ -2202,6 +2219,17 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
         return __builtin_amdgcn_exp2f(df * df * kexp) * w;
     };
     __syncthreads();                                       // pc / wf ready
+    for (int c = tid; c < NP / WRSN_OBS_CH + 2; c += 256) {
+        float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
+        for (int k = 0; k < WRSN_OBS_CH; ++k) {
+            const int n = c * WRSN_OBS_CH + k;
+            if (wf[n] != 0.f) {                                // a zero weight (dead node, padding) reaches nothing
+                const float x = (float)pc[n * 2], y = (float)pc[n * 2 + 1];
+                xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
+            }
+        }
+        bbox[4 * c + 0] = xlo; bbox[4 * c + 1] = xhi; bbox[4 * c + 2] = ylo; bbox[4 * c + 3] = yhi;
+    }
 #ifndef WRSN_OBS_NO_FILL
     for (int n = 0; n < WRSN_OBS_CH; ++n) mine[n * WRSN_OBS_LD] = expand(pcc[n * 2], isx ? wf[n] : 1.f);
 #endif
@@ -2266,7 +2294,10 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
     if (maps_first) { maps234(); __syncthreads(); }
     WRSN_OBS_STAMP(2)
     // one chunk: 2 MFMAs, one expanded element, 2 MFMAs, one expanded element per k-step; the MFMA operands of the next
-    // k-step are fetched from LDS before the current MFMAs are issued, so no MFMA waits for an LDS round trip
+    // k-step are fetched from LDS before the current MFMAs are issued, so no MFMA waits for an LDS round trip.
+    // Nodes are stored in Morton order, so the eight nodes of a chunk are neighbours in the plane; a Gaussian further
+    // than 6.5 bandwidths from every row of a wave's band contributes less than 7e-10 of its peak there, and the wave
+    // then skips the MFMAs of that chunk (it still expands its column of the next one).
     auto chunk = [&](auto with_mfma, const float* Ac, const float* Bc, float* nxt, const double* pn, const float* wn) {
         constexpr bool MF = decltype(with_mfma)::value;
         float a_n = 0.f, b_n[4] = {0.f, 0.f, 0.f, 0.f};
@@ -2297,16 +2328,44 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
 #endif
         }
     };
-    int cur = 0;
-    for (int c0 = 0; c0 < N; c0 += WRSN_OBS_CH, cur ^= 1) {
-        const float* Ac = A + cur * (2 * WRSN_OBS_CH * WRSN_OBS_LD); const float* Bc = Ac + WRSN_OBS_CH * WRSN_OBS_LD;
-        float* nxt = mine + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD);
-        const double* pn = pcc + (c0 + WRSN_OBS_CH) * 2; const float* wn = wf + c0 + WRSN_OBS_CH;
+    // rows / columns (in map units) a chunk's nodes can reach
+    const float rx = 6.5f * (float)hX;
+    const float band_lo = (float)((row0 + 0.5) * unit), band_hi = (float)((row0 + 31.5) * unit);
+    // which chunks have a weighted node that reaches a row of this wave's band (wave-uniform bit masks, <= 128 chunks)
+    const int nchunk = (N + WRSN_OBS_CH - 1) / WRSN_OBS_CH;
+    unsigned long long need_lo = 0ull, need_hi = 0ull;
+    if (band) {
+        for (int c = 0; c < nchunk; ++c) {
+            const bool nd = bbox[4 * c + 0] - rx <= band_hi && bbox[4 * c + 1] + rx >= band_lo;
+            if (c < 64) need_lo |= (unsigned long long)nd << c; else need_hi |= (unsigned long long)nd << (c - 64);
+        }
+    }
+    need_lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(need_lo >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)need_lo);
+    need_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(need_hi >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)need_hi);
+    auto needed = [&](int c) { return (((c < 64) ? (need_lo >> c) : (need_hi >> (c - 64))) & 1ull) != 0ull; };
+    // runs of chunks of one kind, each run in a loop of its own kind: the accumulators stay in registers
+    int cur = 0, c = 0;
+    while (c < nchunk) {
+        const bool kind = needed(c);
+        int e = c + 1;
+        while (e < nchunk && needed(e) == kind) ++e;
 #ifndef WRSN_OBS_NO_MFMA
-        if (band) chunk(WrsnTrue(), Ac, Bc, nxt, pn, wn); else
+        if (kind) {
+            for (; c < e; ++c, cur ^= 1) {
+                const float* Ac = A + cur * (2 * WRSN_OBS_CH * WRSN_OBS_LD); const float* Bc = Ac + WRSN_OBS_CH * WRSN_OBS_LD;
+                float* nxt = mine + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD);
+                chunk(WrsnTrue(), Ac, Bc, nxt, pcc + (c + 1) * WRSN_OBS_CH * 2, wf + (c + 1) * WRSN_OBS_CH);
+                __syncthreads();                           // next chunk complete, this one consumed
+            }
+        } else
 #endif
-        chunk(WrsnFalse(), Ac, Bc, nxt, pn, wn);
-        __syncthreads();                                   // next chunk complete, this one consumed
+        {
+            for (; c < e; ++c, cur ^= 1) {
+                float* nxt = mine + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD);
+                chunk(WrsnFalse(), A, A, nxt, pcc + (c + 1) * WRSN_OBS_CH * 2, wf + (c + 1) * WRSN_OBS_CH);
+                __syncthreads();
+            }
+        }
     }
     WRSN_OBS_STAMP(3)
     // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -2330,4 +2389,4 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
 #endif
 }
 
-static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * (2 * 8 + 4) + 2 * WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * (2 * 8 + 4) + 16 * (NP / WRSN_OBS_CH + 2) + 2 * WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }

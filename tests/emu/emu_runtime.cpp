@@ -42,7 +42,7 @@ void* g_fiber_sp[kMaxThreads];
 std::vector<char> g_stacks;
 const std::function<void()>* g_body;
 bool g_done[kMaxThreads];
-bool g_waiting[kMaxThreads];
+int g_waiting[kMaxThreads];                     // 0 running, 1 at a block-wide rendezvous, 2 at a rendezvous of its wavefront
 unsigned g_cur;
 
 void fiber_entry() {
@@ -54,9 +54,18 @@ void fiber_entry() {
 }  // namespace
 
 void emu_barrier() {
-    g_waiting[g_cur] = true;
+    g_waiting[g_cur] = 1;
     unsigned me = g_cur;
     emu_switch(&g_fiber_sp[me], g_main_sp);      // resumed once every live fiber has arrived
+    threadIdx.x = me;
+}
+
+// rendezvous of the 64 lanes of the caller's wavefront only (wave-level instructions such as MFMA: the waves of a
+// workgroup may issue different numbers of them between two __syncthreads)
+void emu_wave_barrier() {
+    g_waiting[g_cur] = 2;
+    unsigned me = g_cur;
+    emu_switch(&g_fiber_sp[me], g_main_sp);
     threadIdx.x = me;
 }
 
@@ -74,17 +83,28 @@ void emu_run_block(const std::function<void()>& body, unsigned nthreads) {
         g_fiber_sp[t] = sp;
         g_done[t] = false; g_waiting[t] = false;
     }
+    for (unsigned t = 0; t < nthreads; ++t) g_waiting[t] = 0;
     for (;;) {
-        unsigned live = 0, waiting = 0;
+        bool progressed = false;
         for (unsigned t = 0; t < nthreads; ++t) {
-            if (g_done[t]) continue;
+            if (g_done[t] || g_waiting[t]) continue;
             g_cur = t; threadIdx.x = t;
-            g_waiting[t] = false;
             emu_switch(&g_main_sp, g_fiber_sp[t]);
-            if (!g_done[t]) { ++live; if (g_waiting[t]) ++waiting; }
+            progressed = true;
         }
+        unsigned live = 0, at_block = 0;
+        for (unsigned t = 0; t < nthreads; ++t) if (!g_done[t]) { ++live; if (g_waiting[t] == 1) ++at_block; }
         if (live == 0) break;
-        if (waiting != live) { std::fprintf(stderr, "emu: divergent rendezvous (%u of %u fibers waiting)\n", waiting, live); std::abort(); }
-        emu_parity ^= 1;
+        bool released = false;
+        for (unsigned w0 = 0; w0 < nthreads; w0 += 64) {      // wavefront rendezvous first
+            unsigned lw = 0, ww = 0;
+            for (unsigned t = w0; t < w0 + 64 && t < nthreads; ++t) if (!g_done[t]) { ++lw; if (g_waiting[t] == 2) ++ww; }
+            if (lw > 0 && ww == lw) { for (unsigned t = w0; t < w0 + 64 && t < nthreads; ++t) if (!g_done[t]) g_waiting[t] = 0; released = true; }
+        }
+        if (!released && at_block == live) {
+            for (unsigned t = 0; t < nthreads; ++t) g_waiting[t] = 0;
+            emu_parity ^= 1; released = true;
+        }
+        if (!released && !progressed) { std::fprintf(stderr, "emu: divergent rendezvous (%u of %u fibers at the block barrier)\n", at_block, live); std::abort(); }
     }
 }

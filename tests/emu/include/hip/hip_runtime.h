@@ -49,6 +49,7 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 
 // ---- rendezvous primitives implemented in emu_runtime.cpp
 void emu_barrier();
+void emu_wave_barrier();
 extern unsigned char emu_slots[2][256][16];
 extern int emu_parity;
 void emu_run_block(const std::function<void()>& body, unsigned nthreads);
@@ -124,7 +125,7 @@ extern float emu_mfma_a[4][64], emu_mfma_b[4][64];
 inline wrsn_v16f emu_mfma_32x32x2(float a, float b, wrsn_v16f c, int, int, int) {
     const int t = (int)threadIdx.x, w = t >> 6, l = t & 63;
     emu_mfma_a[w][l] = a; emu_mfma_b[w][l] = b;
-    emu_barrier();
+    emu_wave_barrier();
     wrsn_v16f d = c;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
@@ -132,7 +133,7 @@ inline wrsn_v16f emu_mfma_32x32x2(float a, float b, wrsn_v16f c, int, int, int) 
         for (int k = 0; k < 2; ++k) acc = fmaf(emu_mfma_a[w][k * 32 + i], emu_mfma_b[w][k * 32 + j], acc);
         d[r] = acc;
     }
-    emu_barrier();
+    emu_wave_barrier();
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
