@@ -215,6 +215,7 @@ struct Sim {
     double now; int64_t seq;
     double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;   // pending grid items
     int net_phase, net_active, node_phase, frozen, deaths_flag;
+    double teps;                                             // energy margin of the "may a node run dry" tests
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
     double last_minfit;
@@ -284,6 +285,7 @@ struct Sim {
         N = EC()->n_node; T = EC()->n_target;
         cap = EC()->capacity; thr = EC()->threshold; max_time = EC()->max_time;
         inv_a_b2 = (EC()->beta * EC()->beta) / EC()->alpha;
+        teps = 1e-9 * cap;
         err = 0; deaths_flag = 0;
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
@@ -675,7 +677,7 @@ struct Sim {
         NbRegs nbr; load_neighbors(nbr);
         int a = 0, w = 64;
         for (int guard = 0; a < N && guard < 4 * N + 64; ++guard) {
-            if (need_recv) { margin = 2.0 * walk_receivers(nbr, es); need_recv = false; }   // (re-)route for the live status
+            if (need_recv) { (void)walk_receivers(nbr, es); margin = teps; need_recv = false; }   // (re-)route; a range is safe iff nobody ends at / below thr
             const int b = (a + w < N) ? a + w : N;
             if (walk_range(a, b, nbr, es, rrh, gain, margin)) {
                 a = b;
@@ -720,8 +722,11 @@ struct Sim {
                     double rr = rrh[j];
                     double a = E[j] - d1[j];
                     double b = fmin(a + rr, cap) - d2[j];
-                    // a node can only run dry while it pays for an operation: idle nodes never trigger
-                    if ((d1[j] > 0.0 && a - thr < opmax) || (d2[j] > 0.0 && b - thr < opmax)) trig = true;
+                    // Energy only falls between two half-charges, and an operation fails / kills exactly when the energy
+                    // after it is <= thr: with the routing cache valid the second is uneventful iff both segment ends
+                    // stay above thr (teps: far above the rounding of the closed form, far below any operation).  Idle
+                    // nodes never trigger.
+                    if ((d1[j] > 0.0 && a - thr <= teps) || (d2[j] > 0.0 && b - thr <= teps)) trig = true;
                     double ds = d1[j] + d2[j];
                     if (ds > 0.0) mn = fmin(mn, (E[j] - thr - opmax) / ds);
                 }
