@@ -541,8 +541,8 @@ struct Sim {
     // -------------------------------------------------------------- exact k+0.5 instant (a node may run dry this second)
     // Node.py:57-62 + 102-132 process sources in node-id order; a packet is dropped and the node dies as soon as it cannot
     // pay (Node.py:116-117, 126-127), which re-routes everything behind it.  As long as nobody can fail, the order inside a
-    // range of sources does not matter, so the second is replayed range by range in closed form (64 sources, then 8, then
-    // 1) and only the single source whose packets may hit a starving node is walked packet by packet on lane 0.
+    // range of sources does not matter, so the second is replayed range by range in closed form (bisection down to one
+    // source) and only the single source whose packets may hit a starving node is walked packet by packet on lane 0.
     struct WalkRec { double E; int32_t rcv; float es; };      // LDS record for the packet-by-packet walk
 
     WDEV int live_receiver(int i, double* es) {               // Node.find_receiver of an arbitrary node (lane 0, after a death)
@@ -675,16 +675,13 @@ struct Sim {
         double margin = 0.0;
         bool any_death = false, need_recv = true;
         NbRegs nbr; load_neighbors(nbr);
-        int a = 0, w = 64;
-        for (int guard = 0; a < N && guard < 4 * N + 64; ++guard) {
+        // Everything that is left is tried in one closed form; a range that fails is bisected (its first half is tested,
+        // committed if it is safe) until the one source whose packets meet the starving node is isolated: about
+        // log2(N) + 2 range evaluations per death.
+        int a = 0, hi = N; bool hi_fails = false;            // hi_fails: [a, hi) is known to contain a failure
+        for (int guard = 0; a < N && guard < 16 * N + 64; ++guard) {
             if (need_recv) { (void)walk_receivers(nbr, es); margin = teps; need_recv = false; }   // (re-)route; a range is safe iff nobody ends at / below thr
-            const int b = (a + w < N) ? a + w : N;
-            if (walk_range(a, b, nbr, es, rrh, gain, margin)) {
-                a = b;
-                if ((a & 63) == 0) w = 64; else if ((a & 7) == 0 && w < 8) w = 8;   // widen again at aligned boundaries
-            } else if (w > 1) {
-                w = (w == 64) ? 8 : 1;                       // somebody may starve in [a, b): look closer
-            } else {
+            if (hi_fails && hi - a <= 1) {
                 const int deaths = walk_single(a, es, rrh, gain);
                 if (deaths > 0) {
                     any_death = true; need_recv = true;      // everything behind the dead node is re-routed
@@ -694,9 +691,12 @@ struct Sim {
                         if (((am >> j) & 1u) && !(SLS()[i] & 1)) { am &= ~(1u << j); CS[j] = 0.0; d1[j] = 0.0; d2[j] = 0.0; }   // Node.check_status
                     }
                 }
-                a += 1;
-                if ((a & 63) == 0) w = 64; else if ((a & 7) == 0) w = 8;
+                a += 1; hi = N; hi_fails = false;
+                continue;
             }
+            const int b = hi_fails ? a + (hi - a) / 2 : N;
+            if (walk_range(a, b, nbr, es, rrh, gain, margin)) { a = b; if (a >= hi) { hi = N; hi_fails = false; } }
+            else { hi = b; hi_fails = true; }
         }
         // log_energy of the second: every operation of a surviving node succeeded = start + half-charge gained - end
 #pragma unroll
