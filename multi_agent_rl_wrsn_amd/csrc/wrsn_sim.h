@@ -170,6 +170,16 @@ WDEV double fast_rcp(double x) {
 }
 
 // ------------------------------------------------------------------ the per-environment simulator
+// ------------------------------------------------------------------ wave-uniform values
+// A value every lane holds identically (clocks, sequence numbers, counters, constants) is moved to scalar registers with
+// v_readfirstlane: it then costs SGPRs (which spill into VGPR lanes, 64 per register) instead of a VGPR per value.
+WDEV int wu(int v) { return __builtin_amdgcn_readfirstlane(v); }
+WDEV double wu(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+WDEV int64_t wu(int64_t v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll)); const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((int64_t)hi << 32) | (int64_t)lo;
+}
+
 // ------------------------------------------------------------------ LDS gathers
 // Eight data-dependent LDS words in ONE round trip: the ds_read are issued back to back and waited for once.  Written
 // as inline assembly because the register-pressure heuristics of the scheduler otherwise emit read / wait / use eight
@@ -215,6 +225,7 @@ struct Sim {
     double now; int64_t seq;
     double net_time; int64_t net_seq; double ur_time; int64_t ur_seq; double node_time; int64_t node_seq;   // pending grid items
     int net_phase, net_active, node_phase, frozen, deaths_flag;
+    int uns_cnt, uns_node;                                   // walk_range: how many nodes were unsafe, and (one of) them
     double teps;                                             // energy margin of the "may a node run dry" tests
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
@@ -282,10 +293,10 @@ struct Sim {
             for (int w = lane; w < (int)(sizeof(WrsnEnvConst) / 8); w += 64) l[w] = g[w];
         }
         __syncthreads();
-        N = EC()->n_node; T = EC()->n_target;
-        cap = EC()->capacity; thr = EC()->threshold; max_time = EC()->max_time;
-        inv_a_b2 = (EC()->beta * EC()->beta) / EC()->alpha;
-        teps = 1e-9 * cap;
+        N = wu(EC()->n_node); T = wu(EC()->n_target);
+        cap = wu(EC()->capacity); thr = wu(EC()->threshold); max_time = wu(EC()->max_time);
+        inv_a_b2 = wu((EC()->beta * EC()->beta) / EC()->alpha);
+        teps = wu(1e-9 * cap);
         err = 0; deaths_flag = 0;
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
@@ -374,13 +385,13 @@ struct Sim {
             am |= (unsigned)(ls & 1) << j;
         }
         const WrsnEnvDyn* dy = a.dyn + env;
-        now = dy->now; seq = dy->seq; net_time = dy->net_time; net_seq = dy->net_seq; ur_time = dy->ur_time; ur_seq = dy->ur_seq;
-        node_time = dy->node_time; node_seq = dy->node_seq; last_minfit = dy->last_minfit; opmax = dy->opmax;
-        n_ticks = dy->n_ticks; n_exact = dy->n_exact;
-        net_phase = dy->net_phase; net_active = dy->net_active; node_phase = dy->node_phase; alive = dy->alive;
-        levels_dirty = dy->levels_dirty; cache_dirty = dy->cache_dirty; irreg = dy->irreg; ring_len = dy->ring_len;
-        ring_head = dy->ring_head; safe_ticks = dy->safe_ticks; frozen = dy->frozen;
-        log_pending = dy->log_pending;
+        now = wu(dy->now); seq = wu(dy->seq); net_time = wu(dy->net_time); net_seq = wu(dy->net_seq); ur_time = wu(dy->ur_time); ur_seq = wu(dy->ur_seq);
+        node_time = wu(dy->node_time); node_seq = wu(dy->node_seq); last_minfit = wu(dy->last_minfit); opmax = wu(dy->opmax);
+        n_ticks = wu(dy->n_ticks); n_exact = wu(dy->n_exact);
+        net_phase = wu(dy->net_phase); net_active = wu(dy->net_active); node_phase = wu(dy->node_phase); alive = wu(dy->alive);
+        levels_dirty = wu(dy->levels_dirty); cache_dirty = wu(dy->cache_dirty); irreg = wu(dy->irreg); ring_len = wu(dy->ring_len);
+        ring_head = wu(dy->ring_head); safe_ticks = wu(dy->safe_ticks); frozen = wu(dy->frozen);
+        log_pending = wu(dy->log_pending);
         const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = ga[w];
         const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)STH();
@@ -466,7 +477,6 @@ struct Sim {
                 if ((ls & 1) && (ls >> 1) == 0 && (hit & 1)) { SLS()[i] = ((cur + 2) << 1) | 1; ch = true; }   // alive, level == -1
             }
             __syncthreads();
-            WRSN_PROF_CNT(21, 1)
             if (!wv_any(ch)) break;
         }
         bool changed = false;
@@ -591,11 +601,11 @@ struct Sim {
             }
         }
         __syncthreads();
-        double en[NPL], gn[NPL]; bool unsafe = false;
+        double en[NPL], gn[NPL]; unsigned unsafe_m = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane;
-            en[j] = E[j]; gn[j] = 0.0;
+            en[j] = E[j]; gn[j] = 0.0; bool unsafe = false;
             if ((am >> j) & 1u) {
                 const double per = er + es[j];
                 double e = E[j] - (double)c1[i] * per;           // sources with a lower id: before the node's own wake
@@ -610,14 +620,55 @@ struct Sim {
                 }
                 en[j] = e;
             }
+            if (unsafe) unsafe_m |= 1u << j;
         }
-        const bool bad = wv_any(unsafe);
+        const bool bad = wv_any(unsafe_m != 0);
+        if (bad) {                                           // who: lets exact_walk go straight to the critical source
+            uns_cnt = 0; uns_node = -1;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const unsigned long long mk = __ballot((unsafe_m >> j) & 1u);
+                uns_cnt += __popcll(mk);
+                if (mk && uns_node < 0) uns_node = j * 64 + __popcll((mk & (~mk + 1ull)) - 1ull);
+            }
+        }
         if (!bad) {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) { E[j] = en[j]; gain[j] += gn[j]; }
         }
         __syncthreads();
         return !bad;
+    }
+
+    // The range [a, b) failed because exactly one node v would end at / below thr.  Energy of v only falls between its
+    // half-charges, so the first source after whose packets v is at / below thr is found by replaying v alone: sources
+    // whose route passes v cost it (er + es_v) per packet, its own wake adds the half-charge and costs es_v per own
+    // packet.  Returns that source (to be walked packet by packet; everything before it is safe), or -1.
+    WDEV int locate_failure(int a, int b, int v, const NbRegs& nbr, const double (&es)[NPL], const double (&rrh)[NPL]) {
+        double* pv = SU(); int32_t* rq = (int32_t*)(SU() + 8);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int q = j * 64 + lane;
+            if (q == v) { pv[0] = E[j]; pv[1] = EC()->e_recv + es[j]; pv[2] = es[j]; pv[3] = rrh[j]; pv[4] = (double)nbr.ncov[j]; }
+            int r = 0;
+            if (q >= a && q < b && q != v && ((am >> j) & 1u) && nbr.ncov[j] > 0) {
+                int u = SRCV()[q], guard = 0; bool hit = false;
+                while (u >= 0 && guard++ < N) { hit = hit || (u == v); u = SRCV()[u]; }
+                r = hit ? nbr.ncov[j] : 0;
+            }
+            rq[q] = r;
+        }
+        __syncthreads();
+        double e = pv[0]; const double per = pv[1], own = pv[2] * pv[4], rrv = pv[3];
+        int found = -1;
+        for (int q = a; q < b && found < 0; ++q) {
+            const int r = rq[q];
+            if (q == v) { e = fmin(e + rrv, cap) - own; if (e - thr <= teps) found = q; }
+            else if (r > 0) { e -= per * (double)r; if (e - thr <= teps) found = q; }
+        }
+        __syncthreads();
+        return found;
     }
 
     // one source, packet by packet (lane 0), exactly as Node.send_package / receive_package; returns #deaths
@@ -678,11 +729,13 @@ struct Sim {
         // Everything that is left is tried in one closed form; a range that fails is bisected (its first half is tested,
         // committed if it is safe) until the one source whose packets meet the starving node is isolated: about
         // log2(N) + 2 range evaluations per death.
-        int a = 0, hi = N; bool hi_fails = false;            // hi_fails: [a, hi) is known to contain a failure
+        int a = 0, hi = N, hint = -1; bool hi_fails = false; // hi_fails: [a, hi) is known to contain a failure; hint: believed first critical source
         for (int guard = 0; a < N && guard < 16 * N + 64; ++guard) {
-            if (need_recv) { (void)walk_receivers(nbr, es); margin = teps; need_recv = false; }   // (re-)route; a range is safe iff nobody ends at / below thr
+            if (need_recv) { WRSN_PROF_MARK(x0_) (void)walk_receivers(nbr, es); margin = teps; need_recv = false; WRSN_PROF_MARK(x1_) WRSN_PROF_SPAN(16, x0_, x1_) }   // (re-)route; a range is safe iff nobody ends at / below thr
             if (hi_fails && hi - a <= 1) {
+                WRSN_PROF_MARK(x2_)
                 const int deaths = walk_single(a, es, rrh, gain);
+                WRSN_PROF_MARK(x3_) WRSN_PROF_SPAN(17, x2_, x3_) WRSN_PROF_CNT(18, 1)
                 if (deaths > 0) {
                     any_death = true; need_recv = true;      // everything behind the dead node is re-routed
 #pragma unroll
@@ -691,12 +744,24 @@ struct Sim {
                         if (((am >> j) & 1u) && !(SLS()[i] & 1)) { am &= ~(1u << j); CS[j] = 0.0; d1[j] = 0.0; d2[j] = 0.0; }   // Node.check_status
                     }
                 }
-                a += 1; hi = N; hi_fails = false;
+                a += 1; hi = N; hi_fails = false; hint = -1;
                 continue;
             }
-            const int b = hi_fails ? a + (hi - a) / 2 : N;
-            if (walk_range(a, b, nbr, es, rrh, gain, margin)) { a = b; if (a >= hi) { hi = N; hi_fails = false; } }
-            else { hi = b; hi_fails = true; }
+            const bool use_hint = hi_fails && hint > a && hint < hi;
+            const int b = hi_fails ? (use_hint ? hint : a + (hi - a) / 2) : N;
+            hint = -1;
+            WRSN_PROF_MARK(x4_)
+            const bool okr_ = walk_range(a, b, nbr, es, rrh, gain, margin);
+            WRSN_PROF_MARK(x5_) WRSN_PROF_SPAN(19, x4_, x5_) WRSN_PROF_CNT(20, 1)
+            if (okr_) { a = b; if (a >= hi) { hi = N; hi_fails = false; } }
+            else {
+                hi = b; hi_fails = true;
+                if (uns_cnt == 1 && hi - a > 2) {            // one starving node: go straight to the source that meets it
+                    WRSN_PROF_CNT(21, 1)
+                    const int q = locate_failure(a, hi, uns_node, nbr, es, rrh);
+                    if (q >= a) { hi = q + 1; hint = q; }
+                }
+            }
         }
         // log_energy of the second: every operation of a surviving node succeeded = start + half-charge gained - end
 #pragma unroll
@@ -1525,7 +1590,7 @@ struct Sim {
             break;
         default: break;
         }
-        WRSN_PROF_MARK(sr1_) WRSN_PROF_SPAN(16, sr0_, sr1_)
+        
         for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
             WRSN_PROF_MARK(sc0_)
             if (!ev.valid) {                                 // charger / condition state only changes when one of them fires
@@ -1552,7 +1617,7 @@ struct Sim {
 #undef WRSN_CONSIDER
                 ev.kind = kind_; ev.idx = idx_; ev.time = bt_; ev.prio = bp_; ev.seq = bs_; ev.t2 = t2_; ev.valid = 1; ev.uf = -1;
             }
-            WRSN_PROF_MARK(sc1_) WRSN_PROF_SPAN(17, sc0_, sc1_)
+            
             const int kind = ev.kind, idx = ev.idx, bp = ev.prio; const double bt = ev.time; const int64_t bs = ev.seq;
             const bool have_ev = kind >= 0;
             // next grid item (wave-uniform registers; lane 0 holds the same copy)
@@ -1570,7 +1635,7 @@ struct Sim {
                 WRSN_PROF_MARK(uf0_)
                 ev.uf = ur_flags();
                 if (ev.uf & 1) ur_build(); else SURN()[0] = 0;
-                WRSN_PROF_MARK(uf1_) WRSN_PROF_SPAN(18, uf0_, uf1_)
+                
                 WRSN_PROF_EV(21, 1) WRSN_PROF_EV(23, SURN()[0])
             }
             if (have_grid && gt < t_lim) {
@@ -1593,7 +1658,7 @@ struct Sim {
             if (kind == 3) {
                 WRSN_PROF_MARK(tf0_)
                 int r = thread_fire(idx);
-                WRSN_PROF_MARK(tf1_) WRSN_PROF_SPAN(19, tf0_, tf1_) WRSN_PROF_CNT(20, 1)
+                
                 if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; *pend_out = r; return r; }
                 // the same process usually owns the next event too (its hops at one instant, or its next timeout is
                 // the earliest): no rescan when nothing else can come first
@@ -1636,7 +1701,7 @@ struct Sim {
             __syncthreads();
             WRSN_PROF_ADD(0) WRSN_PROF_CNT(12, 1) }
             const int req = SREQ()[0], arg = SREQ()[1];
-            now = SREQD()[1]; seq = ((const int64_t*)SREQD())[2];      // lane 0 advanced them while firing events
+            now = wu(SREQD()[1]); seq = wu(((const int64_t*)SREQD())[2]);      // lane 0 advanced them while firing events
             if (req == REQ_STOP) break;
             work += 16;
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
