@@ -729,9 +729,16 @@ struct Sim {
         // Everything that is left is tried in one closed form; a range that fails is bisected (its first half is tested,
         // committed if it is safe) until the one source whose packets meet the starving node is isolated: about
         // log2(N) + 2 range evaluations per death.
-        int a = 0, hi = N, hint = -1; bool hi_fails = false; // hi_fails: [a, hi) is known to contain a failure; hint: believed first critical source
+        // node_half found the whole second unsafe with the routing cache (the same closed form as a range evaluation of
+        // [0, N)): that evaluation is not repeated
+        int a = 0, hi = N, hint = -1; bool hi_fails = true;  // hi_fails: [a, hi) is known to contain a failure; hint: believed first critical source
+        bool first = true;
         for (int guard = 0; a < N && guard < 16 * N + 64; ++guard) {
             if (need_recv) { WRSN_PROF_MARK(x0_) (void)walk_receivers(nbr, es); margin = teps; need_recv = false; WRSN_PROF_MARK(x1_) WRSN_PROF_SPAN(16, x0_, x1_) }   // (re-)route; a range is safe iff nobody ends at / below thr
+            if (first) {
+                first = false;
+                if (uns_cnt == 1 && N > 2) { WRSN_PROF_CNT(21, 1) const int q = locate_failure(0, N, uns_node, nbr, es, rrh); if (q >= 0) { hi = q + 1; hint = q; } }
+            }
             if (hi_fails && hi - a <= 1) {
                 WRSN_PROF_MARK(x2_)
                 const int deaths = walk_single(a, es, rrh, gain);
@@ -787,7 +794,7 @@ struct Sim {
         bool fast = true;
         if (safe_ticks > 0) { safe_ticks--; }
         else {
-            bool trig = false; double mn = 1e30;
+            unsigned trig = 0; double mn = 1e30;
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
                 if ((am >> j) & 1u) {
@@ -798,12 +805,21 @@ struct Sim {
                     // after it is <= thr: with the routing cache valid the second is uneventful iff both segment ends
                     // stay above thr (teps: far above the rounding of the closed form, far below any operation).  Idle
                     // nodes never trigger.
-                    if ((d1[j] > 0.0 && a - thr <= teps) || (d2[j] > 0.0 && b - thr <= teps)) trig = true;
+                    if ((d1[j] > 0.0 && a - thr <= teps) || (d2[j] > 0.0 && b - thr <= teps)) trig |= 1u << j;
                     double ds = d1[j] + d2[j];
                     if (ds > 0.0) mn = fmin(mn, (E[j] - thr - opmax) / ds);
                 }
             }
-            fast = !wv_any(trig);
+            fast = !wv_any(trig != 0);
+            if (!fast) {                                     // who: the exact second starts from the critical source when it is one node
+                uns_cnt = 0; uns_node = -1;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const unsigned long long mk = __ballot((trig >> j) & 1u);
+                    uns_cnt += __popcll(mk);
+                    if (mk && uns_node < 0) uns_node = j * 64 + __popcll((mk & (~mk + 1ull)) - 1ull);
+                }
+            }
             if (fast) { double m = wv_min(mn); safe_ticks = (m > 4.0) ? (int)fmin(m - 3.0, 1.0e6) : 0; }
         }
         if (fast) {
