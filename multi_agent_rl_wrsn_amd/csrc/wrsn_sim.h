@@ -520,15 +520,17 @@ struct Sim {
             SRCV()[i] = r; c1[i] = 0; c2[i] = 0;
         }
         __syncthreads();
+        {   // relays per second of every node: the routes of a lane's sources are walked together (overlapping LDS round trips)
+            int v[NPL];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane;
-            if (((am >> j) & 1u) && rc[j] >= 0) {
-                int n = nbr.ncov[j];
-                if (n > 0) {
-                    int a = rc[j], guard = 0;
-                    while (a >= 0 && guard++ < N) { atomicAdd((i < a) ? &c1[a] : &c2[a], n); a = SRCV()[a]; }
+            for (int j = 0; j < NPL; ++j) v[j] = (((am >> j) & 1u) && rc[j] >= 0 && nbr.ncov[j] > 0) ? rc[j] : -1;
+            for (int guard = 0; guard < N; ++guard) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (v[j] >= 0) { const int i = j * 64 + lane; atomicAdd((i < v[j]) ? &c1[v[j]] : &c2[v[j]], nbr.ncov[j]); v[j] = SRCV()[v[j]]; any = true; }
                 }
+                if (!any) break;
             }
         }
         __syncthreads();
@@ -592,12 +594,18 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) { c1[j * 64 + lane] = 0; c2[j * 64 + lane] = 0; }
         __syncthreads();
+        {   // every source adds its packets to each relay of its route; the (up to NPL) routes of a lane are walked together so
+            // that their LDS round trips overlap
+            int v[NPL];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int q = j * 64 + lane;
-            if (q >= a && q < b && ((am >> j) & 1u)) {
-                const int n = nbr.ncov[j]; int v = SRCV()[q], guard = 0;
-                if (n > 0) while (v >= 0 && guard++ < N) { atomicAdd((q < v) ? &c1[v] : &c2[v], n); v = SRCV()[v]; }
+            for (int j = 0; j < NPL; ++j) { const int q = j * 64 + lane; v[j] = (q >= a && q < b && ((am >> j) & 1u) && nbr.ncov[j] > 0) ? SRCV()[q] : -1; }
+            for (int guard = 0; guard < N; ++guard) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    if (v[j] >= 0) { const int q = j * 64 + lane; atomicAdd((q < v[j]) ? &c1[v[j]] : &c2[v[j]], nbr.ncov[j]); v[j] = SRCV()[v[j]]; any = true; }
+                }
+                if (!any) break;
             }
         }
         __syncthreads();
@@ -654,7 +662,7 @@ struct Sim {
             int r = 0;
             if (q >= a && q < b && q != v && ((am >> j) & 1u) && nbr.ncov[j] > 0) {
                 int u = SRCV()[q], guard = 0; bool hit = false;
-                while (u >= 0 && guard++ < N) { hit = hit || (u == v); u = SRCV()[u]; }
+                while (u >= 0 && !hit && guard++ < N) { hit = (u == v); u = SRCV()[u]; }
                 r = hit ? nbr.ncov[j] : 0;
             }
             rq[q] = r;
