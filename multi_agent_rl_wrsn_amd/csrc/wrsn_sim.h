@@ -557,14 +557,6 @@ struct Sim {
     // source) and only the single source whose packets may hit a starving node is walked packet by packet on lane 0.
     struct WalkRec { double E; int32_t rcv; float es; };      // LDS record for the packet-by-packet walk
 
-    WDEV int live_receiver(int i, double* es) {               // Node.find_receiver of an arbitrary node (lane 0, after a death)
-        const int lvl = (SLS()[i] >> 1) - 1;
-        const bool ovf = !kNbReg || ((NFLAGS()[i] >> 1) & 1);
-        U4 v; v.x = v.y = v.z = v.w = 0xFFFFFFFFu;
-        if (!ovf) v = NBP()[i];
-        return find_receiver(v.x, v.y, v.z, v.w, ovf, i, lvl, es);
-    }
-
     // receivers + send cost of every alive node for the current (live status, last levels); returns max op cost
     WDEV double walk_receivers(const NbRegs& nbr, double (&es)[NPL]) {
         double opm = EC()->e_recv;
@@ -680,30 +672,31 @@ struct Sim {
     }
 
     // one source, packet by packet (lane 0), exactly as Node.send_package / receive_package; returns #deaths
-    WDEV int walk_single(int q, double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL]) {
+    // Within one packet the cached receivers stay valid: a death either drops the packet or happens behind it (the sender
+    // dies after paying).  Only the NEXT packets see a changed network, so the walk stops after the first packet with a
+    // death and reports where to go on (SREQ()[3] = next packet, SREQ()[0] = packets of the source); the caller re-routes
+    // with the whole wave and calls again.
+    WDEV int walk_single(int q, int p0, double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL]) {
         WalkRec* rec = (WalkRec*)SU();
         const double er = EC()->e_recv;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane;
-            if (i == q && ((am >> j) & 1u)) { double e2 = fmin(E[j] + rrh[j], cap); gain[j] += e2 - E[j]; E[j] = e2; }   // the source wakes
+            if (p0 == 0 && i == q && ((am >> j) & 1u)) { double e2 = fmin(E[j] + rrh[j], cap); gain[j] += e2 - E[j]; E[j] = e2; }   // the source wakes
             WalkRec w; w.E = E[j]; w.rcv = SRCV()[i]; w.es = (float)es[j];
             rec[i] = w;
         }
         __syncthreads();
         if (lane == 0) {
-            int deaths = 0;
+            int deaths = 0, nc = 0, p = p0;
             if (SLS()[q] & 1) {
-                const int nc = NFLAGS()[q] >> 8;
-                for (int p = 0; p < nc; ++p) {
+                nc = NFLAGS()[q] >> 8;
+                for (; p < nc && deaths == 0; ++p) {
                     int cur = q;
                     for (int hop = 0; hop <= N; ++hop) {
                         WalkRec w = rec[cur];
-                        int r; double esv;
-                        if (deaths == 0) { r = w.rcv; esv = (double)w.es; }
-                        else if (NFLAGS()[cur] & 1) { r = -2; esv = ES_BS()[cur]; }
-                        else r = live_receiver(cur, &esv);
+                        const int r = w.rcv; const double esv = (double)w.es;
                         if (r == -1) { if (w.E <= thr) { SLS()[cur] &= ~1; deaths++; } break; }
                         if (w.E - thr < esv) { rec[cur].E = thr; SLS()[cur] &= ~1; deaths++; break; }
                         double e = w.E - esv;
@@ -717,7 +710,7 @@ struct Sim {
                     }
                 }
             }
-            SREQ()[1] = deaths;
+            SREQ()[1] = deaths; SREQ()[3] = p; SREQ()[0] = nc;
         }
         __syncthreads();
         const int deaths = SREQ()[1];
@@ -749,16 +742,23 @@ struct Sim {
             }
             if (hi_fails && hi - a <= 1) {
                 WRSN_PROF_MARK(x2_)
-                const int deaths = walk_single(a, es, rrh, gain);
-                WRSN_PROF_MARK(x3_) WRSN_PROF_SPAN(17, x2_, x3_) WRSN_PROF_CNT(18, 1)
-                if (deaths > 0) {
-                    any_death = true; need_recv = true;      // everything behind the dead node is re-routed
+                for (int p0 = 0;;) {                         // packet by packet; after a packet with a death the wave re-routes
+                    const int deaths = walk_single(a, p0, es, rrh, gain);
+                    const int next_p = SREQ()[3], nc = SREQ()[0];
+                    __syncthreads();
+                    if (deaths > 0) {
+                        any_death = true;
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) {
-                        const int i = j * 64 + lane;
-                        if (((am >> j) & 1u) && !(SLS()[i] & 1)) { am &= ~(1u << j); CS[j] = 0.0; d1[j] = 0.0; d2[j] = 0.0; }   // Node.check_status
+                        for (int j = 0; j < NPL; ++j) {
+                            const int i = j * 64 + lane;
+                            if (((am >> j) & 1u) && !(SLS()[i] & 1)) { am &= ~(1u << j); CS[j] = 0.0; d1[j] = 0.0; d2[j] = 0.0; }   // Node.check_status
+                        }
+                        (void)walk_receivers(nbr, es);       // everything behind the dead node is re-routed
                     }
+                    if (next_p >= nc) break;
+                    p0 = next_p;
                 }
+                WRSN_PROF_MARK(x3_) WRSN_PROF_SPAN(17, x2_, x3_) WRSN_PROF_CNT(18, 1)
                 a += 1; hi = N; hi_fails = false; hint = -1;
                 continue;
             }
