@@ -349,8 +349,10 @@ struct Sim {
 
     // Node.find_receiver (Node.py:92-100) of node i from its packed neighbour words: the nearest alive neighbour whose
     // level is lower than lvl, -1 if none; *es = energy of sending one packet to it (Node.py:114-115)
-    WDEV int find_receiver(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, bool ovf, int i, int lvl, double* es) const {
-        int r = -1;
+    // *wsel: which packed neighbour (its send cost is NBP_ES()[8 i + wsel]; the caller fetches the costs of all its slots in
+    // one memory round trip), or -1 with the cost in *es (CSR path)
+    WDEV int find_receiver(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, bool ovf, int i, int lvl, int* wsel_out, double* es) const {
+        int r = -1; *wsel_out = -1; *es = 0.0;
         if (kNbReg && !ovf) {
             int wsel = 0; int idx[8], l2[8];
             const unsigned ok = unpack8(p0, p1, p2, p3, i, idx);
@@ -360,9 +362,8 @@ struct Sim {
                 const int e = (int)((ok >> k) & 1u) & l2[k] & (int)(((l2[k] >> 1) - 1) < lvl);
                 r = (e & 1) ? idx[k] : r; wsel = (e & 1) ? k : wsel;
             }
-            *es = (r >= 0) ? NBP_ES()[(size_t)i * 8 + wsel] : 0.0;
+            *wsel_out = (r >= 0) ? wsel : -1;
         } else {
-            *es = 0.0;
             for (int p = NB_OFF()[i]; p < NB_OFF()[i + 1]; ++p) {
                 const int nb = NB_IDX()[p]; const int l2 = SLS()[nb];
                 if ((l2 & 1) && ((l2 >> 1) - 1) < lvl) { r = nb; *es = e_send(NB_DIST()[p]); break; }
@@ -504,7 +505,7 @@ struct Sim {
     // arrive before / after the node's own half-charge (sources with lower / higher id; Node.py:57-62 runs in id order).
     WDEV void rebuild_cache() { WRSN_PROF_T0
         int32_t* c1 = (int32_t*)SU(); int32_t* c2 = c1 + NP;
-        double es[NPL]; int rc[NPL];
+        double es[NPL]; int rc[NPL], wsl[NPL];
         const double er = EC()->e_recv;
         NbRegs nbr; load_neighbors(nbr);
         __syncthreads();
@@ -512,12 +513,17 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             int ls = SLS()[i]; int lvl = (ls >> 1) - 1;
-            int r = -1; double e1 = 0.0;
-            if ((nbr.direct >> j) & 1u) { r = -2; e1 = ES_BS()[i]; }
-            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, lvl, &e1);
-            if (!(ls & 1)) { r = -1; e1 = 0.0; }
-            es[j] = (r != -1) ? e1 : 0.0; rc[j] = r;
+            int r = -1; double e1 = 0.0; int ws = -1;
+            if ((nbr.direct >> j) & 1u) r = -2;
+            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, lvl, &ws, &e1);
+            if (!(ls & 1)) { r = -1; e1 = 0.0; ws = -1; }
+            es[j] = e1; rc[j] = r; wsl[j] = ws;
             SRCV()[i] = r; c1[i] = 0; c2[i] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {                      // send costs of all slots: independent loads, one round trip
+            const int i = j * 64 + lane;
+            if (rc[j] == -2) es[j] = ES_BS()[i]; else if (wsl[j] >= 0) es[j] = NBP_ES()[(size_t)i * 8 + wsl[j]]; else if (rc[j] == -1) es[j] = 0.0;
         }
         __syncthreads();
         {   // relays per second of every node: the routes of a lane's sources are walked together (overlapping LDS round trips)
@@ -561,17 +567,23 @@ struct Sim {
     WDEV double walk_receivers(const NbRegs& nbr, double (&es)[NPL]) {
         double opm = EC()->e_recv;
         __syncthreads();
-        int rc[NPL];
+        int rc[NPL], wsl[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane; int r = -1; double e1 = 0.0;
+            int i = j * 64 + lane; int r = -1; double e1 = 0.0; int ws = -1;
             const int ls = SLS()[i];
-            if ((nbr.direct >> j) & 1u) { r = -2; e1 = ES_BS()[i]; }
-            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, (ls >> 1) - 1, &e1);
-            if (!(ls & 1)) { r = -1; e1 = 0.0; }
-            es[j] = (r != -1) ? e1 : 0.0; rc[j] = r;
-            opm = fmax(opm, es[j]);
+            if ((nbr.direct >> j) & 1u) r = -2;
+            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, (ls >> 1) - 1, &ws, &e1);
+            if (!(ls & 1)) { r = -1; e1 = 0.0; ws = -1; }
+            es[j] = e1; rc[j] = r; wsl[j] = ws;
         }
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {                      // send costs of all slots: independent loads, one round trip
+            const int i = j * 64 + lane;
+            if (rc[j] == -2) es[j] = ES_BS()[i]; else if (wsl[j] >= 0) es[j] = NBP_ES()[(size_t)i * 8 + wsl[j]]; else if (rc[j] == -1) es[j] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) opm = fmax(opm, es[j]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) SRCV()[j * 64 + lane] = rc[j];
