@@ -194,6 +194,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.nbp_es, B * NP * 8))) break;
         if ((rc = dalloc(h, &d.es_bs, B * NP))) break;
         if ((rc = dalloc(h, &d.xorder, B * NP))) break;
+        if ((rc = dalloc(h, &d.adjm, B * NP * 8))) break;
         if ((rc = dalloc(h, &d.tcp, B * (size_t)d.TP * 4))) break;
         if ((rc = alloc_node_arrays(h, &d.live))) break;
         if ((rc = alloc_node_arrays(h, &d.snap))) break;

@@ -254,6 +254,7 @@ struct Sim {
     WDEV const U4* NBP() const { return (const U4*)(dp->nbp + (size_t)env * NP * 4); }
     WDEV const double* NBP_ES() const { return dp->nbp_es + (size_t)env * NP * 8; }
     WDEV const double* ES_BS() const { return dp->es_bs + (size_t)env * NP; }
+    WDEV const U4* ADJM() const { return (const U4*)(dp->adjm + (size_t)env * NP * 8); }   // [NP][4] uint64 neighbourhood masks (nodes 0..255)
     WDEV const U4* TCP() const { return (const U4*)(dp->tcp + (size_t)env * dp->TP * 4); }
     WDEV double* RING() const { return (use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP; }
     WDEV double* LOGBUF() const { return (use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP; }
@@ -448,8 +449,44 @@ struct Sim {
 
     // -------------------------------------------------------------- Network.setLevels + check_targets (Network.py:37-66, 84-85)
     WDEV void set_levels() { WRSN_PROF_T0
-        NbRegs nbr; load_neighbors(nbr);
         int oldlv[NPL];
+        if (NPL <= 4) {
+            // Up to 256 nodes: node sets are NPL 64-bit masks (one ballot per register slot) and the neighbourhood of a
+            // node is a mask of the same shape, built with the topology.  A BFS level is then a handful of ANDs per slot:
+            // no LDS traffic, no barrier.
+            constexpr int W = (NPL <= 4) ? NPL : 1;
+            unsigned long long adj[W][W]; int lv[W]; bool al[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const int i = j * 64 + lane;
+                const U4 lo = ADJM()[(size_t)i * 2], hi = ADJM()[(size_t)i * 2 + 1];
+                const unsigned long long m[4] = {((unsigned long long)lo.y << 32) | lo.x, ((unsigned long long)lo.w << 32) | lo.z,
+                                                 ((unsigned long long)hi.y << 32) | hi.x, ((unsigned long long)hi.w << 32) | hi.z};
+#pragma unroll
+                for (int w = 0; w < W; ++w) adj[j][w] = m[w];
+                const int ls = SLS()[i]; oldlv[j] = (ls >> 1) - 1;
+                al[j] = (ls & 1) != 0;
+                lv[j] = (al[j] && (NFLAGS()[i] & 1)) ? 1 : -1;
+            }
+            for (int cur = 1; cur <= N; ++cur) {
+                unsigned long long F[W]; unsigned long long anyf = 0ull;
+#pragma unroll
+                for (int w = 0; w < W; ++w) { F[w] = __ballot(al[w] && lv[w] == cur); anyf |= F[w]; }
+                if (anyf == 0ull) break;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    unsigned long long h = 0ull;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) h |= adj[j][w] & F[w];
+                    if (al[j] && lv[j] == -1 && h != 0ull) lv[j] = cur + 1;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < W; ++j) SLS()[j * 64 + lane] = ((lv[j] + 1) << 1) | (al[j] ? 1 : 0);
+            __syncthreads();
+        } else {
+        NbRegs nbr; load_neighbors(nbr);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
@@ -479,6 +516,7 @@ struct Sim {
             }
             __syncthreads();
             if (!wv_any(ch)) break;
+        }
         }
         bool changed = false;
 #pragma unroll
@@ -2014,6 +2052,7 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     int32_t *ncov = d.ncov + nb, *nflags = d.nflags + nb;
     uint32_t* nbp = d.nbp + nb * 4; double* nbp_es = d.nbp_es + nb * 8; double* es_bs = d.es_bs + nb;
     uint32_t* tcp = d.tcp + (size_t)env * d.TP * 4;
+    uint32_t* adjm = d.adjm + nb * 8;
     // energy of sending one packet over distance dd (Node.py:114-115), the formula of Sim::e_send
     const double d0_ = sqrt(ec->efs / ec->emp);
     auto e_send_t = [&](double dd) { const double dq = dd * dd; return ((dd <= d0_) ? (ec->et + ec->efs * dq) : (ec->et + ec->emp * (dq * dq))) * ec->package_size; };
@@ -2074,6 +2113,9 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
             }
             for (int w = 0; w < 8; ++w) nbp_es[i * 8 + w] = (fits && w < cnt) ? e_send_t(nb_dist[off + w]) : 0.0;
             if (cnt > 8) nflags[i] |= 2;
+            unsigned long long am4[4] = {0ull, 0ull, 0ull, 0ull};                 // neighbourhood as a node-set mask (nodes 0..255)
+            if (fits) for (int p = off; p < off + cnt; ++p) { const int k = nb_idx[p]; if (k < 256) am4[k >> 6] |= 1ull << (k & 63); }
+            for (int w = 0; w < 4; ++w) { adjm[(size_t)i * 8 + 2 * w] = (uint32_t)am4[w]; adjm[(size_t)i * 8 + 2 * w + 1] = (uint32_t)(am4[w] >> 32); }
         }
         base += __shfl(incl, 63);
     }

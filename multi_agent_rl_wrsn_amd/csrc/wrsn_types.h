@@ -91,6 +91,7 @@ struct WrsnDev {
     uint32_t *nbp;                    // [B][NP][4]  the eight nearest neighbour ids, 16 bit each (0xFFFF none), sorted by (distance, id)
     double *nbp_es;                   // [B][NP][8]  energy of sending one packet to that neighbour
     double *es_bs;                    // [B][NP]     energy of sending one packet to the base station
+    uint32_t *adjm;                   // [B][NP][8]  neighbourhood of a node as a set mask over nodes 0..255 (4 x 64 bit; level BFS of N <= 256)
     int32_t *xorder;                  // [B][NP]     node ids in Morton order of their position (observation kernel)
     uint32_t *tcp;                    // [B][TP][4]  the first eight covering node ids of a target, packed alike
     WrsnNodeArrays live, snap;        // current state / post-warm-up snapshot
