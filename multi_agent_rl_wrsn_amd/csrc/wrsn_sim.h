@@ -1244,7 +1244,9 @@ struct Sim {
     // next item would not be strictly earlier than `t_limit` (the next charger / condition event).  When no node is
     // being charged, no reward priority is consumed, the consumption window is uniform and no node can run dry, whole
     // seconds are skipped in closed form (E -= j * (d1 + d2)).
-    WDEV void grid_run(double t_limit, bool one, bool ur_flag) {
+    // `tie_seq` >= 0: the limit is a NORMAL-priority event with that sequence number, and the grid items AT t_limit that
+    // were scheduled before it (smaller sequence number) go first too -- one service instead of one per item.
+    WDEV void grid_run(double t_limit, bool one, bool ur_flag, int64_t tie_seq) {
         deaths_flag = 0;
         // Node.energyRR only changes when lane 0 connects / disconnects a charger, i.e. between two grid services
         const bool any_rr = SREQ()[2] > 0;
@@ -1257,7 +1259,7 @@ struct Sim {
             int k = 1; double bt = ur_time; int64_t bs = ur_seq;
             if (node_time < bt || (node_time == bt && node_seq < bs)) { k = 2; bt = node_time; bs = node_seq; }
             if (net_active && (net_time < bt || (net_time == bt && net_seq < bs))) { k = 0; bt = net_time; bs = net_seq; }
-            if (!one && !(bt < t_limit)) break;
+            if (!one && !(bt < t_limit || (tie_seq >= 0 && bt == t_limit && bs < tie_seq))) break;
             bool do_ur = false, fused = false; int nrep = 0;
             const double kk = floor(bt);
             // ---- canonical start of a second (setLevels@k+0.1 is a no-op, nodes@k+0.5, reward/alive-check/nodes@k+1.0) on
@@ -1718,9 +1720,13 @@ struct Sim {
                 
                 WRSN_PROF_EV(21, 1) WRSN_PROF_EV(23, SURN()[0])
             }
-            if (have_grid && gt < t_lim) {
+            // items AT the event's instant that were scheduled before it precede it as well (same time, same NORMAL priority,
+            // smaller sequence number): the service may take them along
+            const bool tie_ok = have_ev && t_lim == bt && bp == WRSN_NORMAL;
+            if (have_grid && (gt < t_lim || (tie_ok && gt == bt && gs < bs))) {
                 const int uf = ev.uf;
                 if (uf & 2) { ff_sync_all(gt); ur_build(); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
+                else if (tie_ok) { *arg = 2; ((int64_t*)SREQD())[3] = bs; }
                 else *arg = 0;
                 *t_lim_out = t_lim; *flags_out = uf & 1;
                 WRSN_PROF_EV(19, 1) WRSN_PROF_EV(20, (uf & 2) ? 1 : 0)
@@ -1786,7 +1792,7 @@ struct Sim {
             work += 16;
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
-            case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], arg != 0, SREQ()[3] != 0); WRSN_PROF_ADD(1) } break;
+            case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { svc = precheck(arg); } break;
             case REQ_CONN: { conn_build(arg); } break;
             default: break;
