@@ -78,7 +78,7 @@ int alloc_node_arrays(wrsn_handle* h, WrsnNodeArrays* a) {
     if ((rc = dalloc(h, &a->ls, B * NP))) return rc;
     if ((rc = dalloc(h, &a->rcv, B * NP))) return rc;
     if ((rc = dalloc(h, &a->conn, B * WRSN_MAX_MC * WRSN_CONN_CAP))) return rc;
-    if ((rc = dalloc(h, &a->conn_rate, B * WRSN_MAX_MC * WRSN_CONN_CAP))) return rc;
+    if ((rc = dalloc(h, &a->conn_xy, B * WRSN_MAX_MC * WRSN_CONN_CAP * 2))) return rc;
     if ((rc = dalloc(h, &a->dyn, B))) return rc;
     return 0;
 }

@@ -271,8 +271,8 @@ struct Sim {
     WDEV WrsnThread* STH() const { return (WrsnThread*)(SAG() + M); }
     WDEV double* SCT() const { return (double*)(STH() + 2 * M); }
     WDEV int64_t* SCS() const { return (int64_t*)(SCT() + (M + 1)); }
-    WDEV double* SCONNRATE() const { return (double*)(SCS() + (M + 1)); }
-    WDEV double* SURRATE() const { return SCONNRATE() + M * WRSN_CONN_CAP; }
+    WDEV double* SCONNXY() const { return (double*)(SCS() + (M + 1)); }                 // [M][CONN_CAP][2] position of every connected node
+    WDEV double* SURRATE() const { return SCONNXY() + 2 * M * WRSN_CONN_CAP; }
     WDEV double* SURACC() const { return SURRATE() + M * WRSN_CONN_CAP; }
     WDEV double* SREQD() const { return SURACC() + M * WRSN_CONN_CAP; }                 // [0] time limit, [1] now, [2] seq (as int64), [3] spare
     WDEV Scalar* SS() const { return (Scalar*)(SREQD() + 4); }
@@ -399,8 +399,8 @@ struct Sim {
         const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)STH();
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = gt[w];
         const int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        const double* gr = a.conn_rate + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { SCONN()[w] = gc[w]; SCONNRATE()[w] = gr[w]; }
+        const double* gr = a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2;
+        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { SCONN()[w] = gc[w]; SCONNXY()[2 * w] = gr[2 * w]; SCONNXY()[2 * w + 1] = gr[2 * w + 1]; }
         for (int w = lane; w <= M; w += 64) { SCTR()[w] = 0; SCP()[w] = 0; SCA()[w] = 0; SCT()[w] = 0; SCS()[w] = 0; }
         if (lane == 0) { SREQ()[0] = 0; SREQ()[1] = 0; SREQ()[2] = dy->n_connected; SS()->n_events = dy->n_events; SURN()[0] = 0; }
         __syncthreads();
@@ -435,8 +435,8 @@ struct Sim {
         uint64_t* gt = (uint64_t*)dy->th; const uint64_t* lt = (const uint64_t*)STH();
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) gt[w] = lt[w];
         int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        double* gr = a.conn_rate + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { gc[w] = SCONN()[w]; gr[w] = SCONNRATE()[w]; }
+        double* gr = a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2;
+        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { gc[w] = SCONN()[w]; gr[2 * w] = SCONNXY()[2 * w]; gr[2 * w + 1] = SCONNXY()[2 * w + 1]; }
         WRSN_PROF_ADD(11)
     }
 
@@ -915,9 +915,12 @@ struct Sim {
         log_pending = 0; n_ticks++;
     }
 
-    WDEV double conn_rate_of(int m, int k, int i) const {    // alpha / (dist(node, charger) + beta)^2 (Node.py:137, WRSN.py:122)
-        if (SAG()[m].loc[0] == SAG()[m].conn_loc[0] && SAG()[m].loc[1] == SAG()[m].conn_loc[1]) return SCONNRATE()[m * WRSN_CONN_CAP + k];
-        double dd = dist2(NX()[i], NY()[i], SAG()[m].loc[0], SAG()[m].loc[1]) + EC()->beta;
+    // alpha / (dist(node, charger) + beta)^2 (Node.py:137, WRSN.py:122) of connected node k of charger m at the charger's
+    // CURRENT location (a stale "charging" charger may be on the move); node positions were cached by conn_build
+    WDEV double conn_rate_of(int m, int k, int i) const {
+        (void)i;
+        const double* xy = SCONNXY() + 2 * (m * WRSN_CONN_CAP + k);
+        double dd = dist2(xy[0], xy[1], SAG()[m].loc[0], SAG()[m].loc[1]) + EC()->beta;
         return EC()->alpha / (dd * dd);
     }
 
@@ -1214,22 +1217,22 @@ struct Sim {
     }
 
     // -------------------------------------------------------------- connected_nodes of a charger (MobileCharger.py:55-58)
-    // every node (alive or not) within charging range of the charger, id order; caches the connection rate
+    // every node (alive or not) within charging range of the charger, id order; caches the node positions
     WDEV void conn_build(int a) {
         const double lx = SAG()[a].loc[0], ly = SAG()[a].loc[1];
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
-            double dis = (i < N) ? dist2(NX()[i], NY()[i], lx, ly) : 0.0;
+            const double px = (i < N) ? NX()[i] : 0.0, py = (i < N) ? NY()[i] : 0.0;
+            double dis = (i < N) ? dist2(px, py, lx, ly) : 0.0;
             bool in = (i < N) && (dis <= EC()->charging_range);
             unsigned long long mk = __ballot(in);
             if (in) {
                 int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
                 if (pos < WRSN_CONN_CAP) {
                     SCONN()[a * WRSN_CONN_CAP + pos] = (int16_t)i;
-                    double dd = dis + EC()->beta;
-                    SCONNRATE()[a * WRSN_CONN_CAP + pos] = EC()->alpha / (dd * dd);
+                    SCONNXY()[2 * (a * WRSN_CONN_CAP + pos)] = px; SCONNXY()[2 * (a * WRSN_CONN_CAP + pos) + 1] = py;
                 }
             }
             cnt += __popcll(mk);
@@ -1843,7 +1846,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     for (int w = lane; w < s.M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = 0;
     uint64_t* lt = (uint64_t*)s.STH();
     for (int w = lane; w < 2 * s.M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = 0;
-    for (int w = lane; w < s.M * WRSN_CONN_CAP; w += 64) { s.SCONN()[w] = 0; s.SCONNRATE()[w] = 0.0; }
+    for (int w = lane; w < s.M * WRSN_CONN_CAP; w += 64) { s.SCONN()[w] = 0; s.SCONNXY()[2 * w] = 0.0; s.SCONNXY()[2 * w + 1] = 0.0; }
     for (int w = lane; w <= s.M; w += 64) { s.SCTR()[w] = 0; s.SCP()[w] = 0; s.SCA()[w] = 0; s.SCT()[w] = 0; s.SCS()[w] = 0; }
     __syncthreads();
     if (lane == 0) {

@@ -75,7 +75,7 @@ struct WrsnNodeArrays {
     int32_t *ls;                      // [B][NP]   ((level + 1) << 1) | alive
     int32_t *rcv;                     // [B][NP]   cached receiver: node id, -2 base station, -1 none
     int16_t *conn;                    // [B][MAX_MC][CONN_CAP] connected_nodes of each charger
-    double *conn_rate;                // [B][MAX_MC][CONN_CAP] alpha / (dist + beta)^2 at conn_loc
+    double *conn_xy;                  // [B][MAX_MC][CONN_CAP][2] position of every connected node
     WrsnEnvDyn *dyn;                  // [B]
 };
 
@@ -111,7 +111,7 @@ static inline int wrsn_lds_bytes(int NP, int M) {
     b += 4 * NP * 8;                                  // charging rate, 2 scratch arrays, level/alive + receiver words
     b += M * (int)sizeof(WrsnAgent) + 2 * M * (int)sizeof(WrsnThread);
     b += (M + 1) * (8 + 8);                           // condition times / seqs
-    b += 3 * M * WRSN_CONN_CAP * 8;                   // connection rates, reward-entry rates and accumulators
+    b += 4 * M * WRSN_CONN_CAP * 8;                   // connected-node positions (x, y), reward-entry rates and accumulators
     b += 4 * 8 + WRSN_LDS_SCALAR_BYTES + 4 * 4;       // mailbox doubles, scalar bookkeeping, mailbox ints
     b += 3 * (M + 1) * 4 + 4;                         // condition agent / triggered / pending, reward-entry count
     b += 3 * M * WRSN_CONN_CAP * 2;                   // connected-node ids, reward-entry node / charger
