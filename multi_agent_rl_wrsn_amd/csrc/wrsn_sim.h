@@ -2320,7 +2320,7 @@ struct WrsnFalse { static constexpr bool value = false; };
 #ifndef WRSN_V16F_DEFINED
 typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
 #endif
-__global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
+__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
     extern __shared__ double smem[];
     const int env = blockIdx.x, tid = threadIdx.x;
     const int aid = agent_id[env];
@@ -2332,8 +2332,7 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
     double* pc = smem;                                     // [NP + 2 CH][2]  cx, cy of every node
     float* wf = (float*)(pc + 2 * (NP + 2 * WRSN_OBS_CH)); // [NP + 2 CH] weight as float32 (0: dead / padding)
     float* bbox = wf + NP + 2 * WRSN_OBS_CH;               // [NP / CH + 2][4] x / y range of the weighted nodes of a chunk
-    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // [CH][LD]  weight * g(x - x_n)
-    float* Bm = A + WRSN_OBS_CH * WRSN_OBS_LD;             // [CH][LD]  g(y - y_n); a second (A, B) pair follows: double buffer
+    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // four wave-private (A [CH][32], B [CH][128]) buffer pairs
     const double fx0 = ec->frame[0], fy0 = ec->frame[2];
     const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
     const double unit = 1.0 / G;
@@ -2370,20 +2369,6 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
 #pragma unroll
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // Chunks of CH nodes, double-buffered: while the matrix cores work on chunk c every thread expands its column of
-    // chunk c + 1 (thread tid owns column tid & 127 of the x rows (tid < 128) or of the y rows), one node after every
-    // second MFMA, so the v_exp / LDS-write work sits in the shadow of the 64-cycle MFMAs instead of in a phase of its
-    // own.  The expansion is branch-free: nodes beyond N carry weight 0 (their y row is multiplied by a zero x row) and
-    // columns / rows beyond G are never stored, so neither needs a test.
-    const bool isx = wave < 2; const int col = tid & (WRSN_OBS_LD - 1);
-    const double cen = unit / 2 + col * unit;
-    const float kexp = (isx ? inv2hx : inv2hy) * 1.44269504f;                // exp(t) = 2^(t log2 e)
-    const double* pcc = pc + (isx ? 0 : 1);
-    float* mine = (isx ? A : Bm) + col;                                       // column of this thread in buffer 0
-    auto expand = [&](double p, float w) {
-        const float df = (float)(cen - p);                                   // difference in float64, then float32
-        return __builtin_amdgcn_exp2f(df * df * kexp) * w;
-    };
     __syncthreads();                                       // pc / wf ready
     for (int c = tid; c < NP / WRSN_OBS_CH + 2; c += 256) {
         float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
@@ -2396,17 +2381,14 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
         }
         bbox[4 * c + 0] = xlo; bbox[4 * c + 1] = xhi; bbox[4 * c + 2] = ylo; bbox[4 * c + 3] = yhi;
     }
-#ifndef WRSN_OBS_NO_FILL
-    for (int n = 0; n < WRSN_OBS_CH; ++n) mine[n * WRSN_OBS_LD] = expand(pcc[n * 2], isx ? wf[n] : 1.f);
-#endif
     __syncthreads();
     auto maps234 = [&]() {
     // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.
     // Term rows gx[t][G] (already scaled) and gy[t][G] go to LDS; every thread then produces elements tid, tid+256, ...
     // Even blocks produce them before map 1, odd blocks after it: the blocks of a CU start together, and this way the
     // store-bound phase of one half (3/4 of the observation) overlaps the matrix-core phase of the other half.  The term
-    // rows live in the second chunk buffer, which is free before the main loop starts and after it ends.
-    float* tx = A + 2 * WRSN_OBS_CH * WRSN_OBS_LD; float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
+    // rows live in the (then unused) wave buffers: before the map-1 loop starts and after it ends.
+    float* tx = A; float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
     const WrsnAgent* ag = dy->ag;
     for (int o = 0; o < M; ++o) {
         int mp; double cxo, cyo, hx, hy, val;
@@ -2459,78 +2441,51 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
     const bool maps_first = (blockIdx.x & 1) == 0;
     if (maps_first) { maps234(); __syncthreads(); }
     WRSN_OBS_STAMP(2)
-    // one chunk: 2 MFMAs, one expanded element, 2 MFMAs, one expanded element per k-step; the MFMA operands of the next
-    // k-step are fetched from LDS before the current MFMAs are issued, so no MFMA waits for an LDS round trip.
-    // Nodes are stored in Morton order, so the eight nodes of a chunk are neighbours in the plane; a Gaussian further
-    // than 6.5 bandwidths from every row of a wave's band contributes less than 7e-10 of its peak there, and the wave
-    // then skips the MFMAs of that chunk (it still expands its column of the next one).
-    auto chunk = [&](auto with_mfma, const float* Ac, const float* Bc, float* nxt, const double* pn, const float* wn) {
-        constexpr bool MF = decltype(with_mfma)::value;
-        float a_n = 0.f, b_n[4] = {0.f, 0.f, 0.f, 0.f};
-        if (MF) {
-            a_n = Ac[half * WRSN_OBS_LD + row0 + l31];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b_n[t] = Bc[half * WRSN_OBS_LD + 32 * t + l31];
-        }
-#pragma unroll
-        for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
-            const double p0 = pn[k2 * 2], p1 = pn[k2 * 2 + 2];
-            const float w0r = wn[k2], w1r = wn[k2 + 1];
-            const float w0 = isx ? w0r : 1.f, w1 = isx ? w1r : 1.f;
-            // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
-            const float a = a_n; const float b0 = b_n[0], b1 = b_n[1], b2 = b_n[2], b3 = b_n[3];
-            if (MF && k2 + 2 < WRSN_OBS_CH) {
-                a_n = Ac[(k2 + 2 + half) * WRSN_OBS_LD + row0 + l31];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) b_n[t] = Bc[(k2 + 2 + half) * WRSN_OBS_LD + 32 * t + l31];
-            }
-            if (MF) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0); }
-#ifndef WRSN_OBS_NO_FILL
-            nxt[k2 * WRSN_OBS_LD] = expand(p0, w0);
-#endif
-            if (MF) { acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0); acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0); }
-#ifndef WRSN_OBS_NO_FILL
-            nxt[(k2 + 1) * WRSN_OBS_LD] = expand(p1, w1);
-#endif
-        }
-    };
-    // rows / columns (in map units) a chunk's nodes can reach
+    // Map 1: every wave works on its own 32-row band with LDS buffers of its own and walks only the chunks (eight nodes
+    // each, Morton order: neighbours in the plane) with a weighted node that reaches a row of the band -- a Gaussian
+    // further than 6.5 bandwidths away contributes less than 7e-10 of its peak and is skipped.  Per chunk the wave expands
+    // its 32 x-columns and the 128 y-columns of the eight nodes (20 elements per lane: coordinate difference in float64,
+    // v_exp_f32) and issues the 16 MFMAs.  No workgroup barrier: a band's time follows its own work, and the waves of the
+    // other resident blocks fill the matrix-core and VALU gaps.
+    float* Aw = A + wave * (WRSN_OBS_CH * (32 + WRSN_OBS_LD));   // [CH][32]   weight * g(x_row - x_n) for the band's rows
+    float* Bw = Aw + WRSN_OBS_CH * 32;                           // [CH][128]  g(y - y_n)
+    const float kx = inv2hx * 1.44269504f, ky = inv2hy * 1.44269504f;       // exp(t) = 2^(t log2 e)
+    const double cenx = unit / 2 + (row0 + l31) * unit;                    // this lane's x column (A part: node (l >> 5) + 2 m)
+    const double ceny0 = unit / 2 + l * unit, ceny1 = unit / 2 + (l + 64) * unit;   // its two y columns (B part: node m >> 1)
     const float rx = 6.5f * (float)hX;
     const float band_lo = (float)((row0 + 0.5) * unit), band_hi = (float)((row0 + 31.5) * unit);
-    // which chunks have a weighted node that reaches a row of this wave's band (wave-uniform bit masks, <= 128 chunks)
     const int nchunk = (N + WRSN_OBS_CH - 1) / WRSN_OBS_CH;
-    unsigned long long need_lo = 0ull, need_hi = 0ull;
     if (band) {
         for (int c = 0; c < nchunk; ++c) {
-            const bool nd = bbox[4 * c + 0] - rx <= band_hi && bbox[4 * c + 1] + rx >= band_lo;
-            if (c < 64) need_lo |= (unsigned long long)nd << c; else need_hi |= (unsigned long long)nd << (c - 64);
-        }
-    }
-    need_lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(need_lo >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)need_lo);
-    need_hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(need_hi >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)need_hi);
-    auto needed = [&](int c) { return (((c < 64) ? (need_lo >> c) : (need_hi >> (c - 64))) & 1ull) != 0ull; };
-    // runs of chunks of one kind, each run in a loop of its own kind: the accumulators stay in registers
-    int cur = 0, c = 0;
-    while (c < nchunk) {
-        const bool kind = needed(c);
-        int e = c + 1;
-        while (e < nchunk && needed(e) == kind) ++e;
-#ifndef WRSN_OBS_NO_MFMA
-        if (kind) {
-            for (; c < e; ++c, cur ^= 1) {
-                const float* Ac = A + cur * (2 * WRSN_OBS_CH * WRSN_OBS_LD); const float* Bc = Ac + WRSN_OBS_CH * WRSN_OBS_LD;
-                float* nxt = mine + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD);
-                chunk(WrsnTrue(), Ac, Bc, nxt, pcc + (c + 1) * WRSN_OBS_CH * 2, wf + (c + 1) * WRSN_OBS_CH);
-                __syncthreads();                           // next chunk complete, this one consumed
+            const bool need = __builtin_amdgcn_readfirstlane((int)(bbox[4 * c + 0] - rx <= band_hi && bbox[4 * c + 1] + rx >= band_lo)) != 0;
+            if (!need) continue;
+            const double* pn = pc + (size_t)c * WRSN_OBS_CH * 2; const float* wn = wf + c * WRSN_OBS_CH;
+#ifndef WRSN_OBS_NO_FILL
+#pragma unroll
+            for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {          // A: node (l >> 5) + 2 m, column l & 31
+                const int n = half + 2 * m;
+                const float df = (float)(cenx - pn[n * 2]);         // difference in float64, then float32
+                Aw[n * 32 + l31] = __builtin_amdgcn_exp2f(df * df * kx) * wn[n];
             }
-        } else
+#pragma unroll
+            for (int n = 0; n < WRSN_OBS_CH; ++n) {              // B: node n, columns l and l + 64
+                const double py = pn[n * 2 + 1];
+                const float d0 = (float)(ceny0 - py), d1 = (float)(ceny1 - py);
+                Bw[n * WRSN_OBS_LD + l] = __builtin_amdgcn_exp2f(d0 * d0 * ky);
+                Bw[n * WRSN_OBS_LD + l + 64] = __builtin_amdgcn_exp2f(d1 * d1 * ky);
+            }
 #endif
-        {
-            for (; c < e; ++c, cur ^= 1) {
-                float* nxt = mine + (cur ^ 1) * (2 * WRSN_OBS_CH * WRSN_OBS_LD);
-                chunk(WrsnFalse(), A, A, nxt, pcc + (c + 1) * WRSN_OBS_CH * 2, wf + (c + 1) * WRSN_OBS_CH);
-                __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+#ifndef WRSN_OBS_NO_MFMA
+#pragma unroll
+            for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
+                // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
+                const float a = Aw[(k2 + half) * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bw[(k2 + half) * WRSN_OBS_LD + 32 * t + l31], acc[t], 0, 0, 0);
             }
+#endif
+            __builtin_amdgcn_wave_barrier();                   // the next chunk overwrites the buffers
         }
     }
     WRSN_OBS_STAMP(3)
@@ -2555,4 +2510,4 @@ __global__ void __launch_bounds__(256, 5) wrsn_obs_kernel(WrsnDev d, const int32
 #endif
 }
 
-static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * (2 * 8 + 4) + 16 * (NP / WRSN_OBS_CH + 2) + 2 * WRSN_OBS_CH * WRSN_OBS_LD * 4 * 2 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * (2 * 8 + 4) + 16 * (NP / WRSN_OBS_CH + 2) + 4 * WRSN_OBS_CH * (32 + WRSN_OBS_LD) * 4 + 64; }

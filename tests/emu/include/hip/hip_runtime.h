@@ -99,7 +99,8 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_m
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 inline int emu_readlane(int v, int src) { return emu_exchange(v, src); }
 #define __builtin_amdgcn_readlane emu_readlane
-#define __builtin_amdgcn_readfirstlane(x) (x)   /* only used on wave-uniform values */
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()   /* lanes of one wave are fibers here: order their LDS traffic */   /* only used on wave-uniform values */
 // the LDS gathers of wrsn_sim.h are inline assembly (eight ds_read back to back): plain loads here
 #define WRSN_LDS_GATHER_DEFINED
 inline void wrsn_lds_gather8_b32(const int32_t* base, const int (&idx)[8], int (&out)[8]) { for (int k = 0; k < 8; ++k) out[k] = base[idx[k]]; }
