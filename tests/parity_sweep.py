@@ -1,0 +1,95 @@
+"""TEST INFRASTRUCTURE -- wide parity sweep (uses the test oracle; also run small by test_gpu_parity.py): B synthetic environments stepped side by side on the GPU (blocking
+and budgeted) and by the CPU oracle, whole episodes with resets, every request compared.  Far more cases than the -m gpu
+tests run; intended for spare GPU time after a change to the exact-second / scheduling code."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from concurrent.futures import ThreadPoolExecutor
+from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, VecWRSN, synth_scenario
+from wrsn_oracle import OracleWRSN
+from parity import close
+
+
+def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
+    """returns (requests compared, finished episodes, noise-dependent requests); raises AssertionError on a mismatch"""
+    M = 3
+    scs = [synth_scenario(seed0 + e, N, N) for e in range(B)]
+    env = VecWRSN(scs, None, M, step_budget=budget)
+    ors = [OracleWRSN(s.node_xy, s.target_xy, s.bs_xy, s.node_spec, DEFAULT_MC_SPEC, s.max_time, M) for s in scs]
+    r = env.reset(); env.synchronize()
+    last = [o.reset() for o in ors]
+    rng = np.random.RandomState(seed0)
+    pool = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 8))
+    n_cmp = 0; n_term = 0; n_noise = 0; worst_rew = 0.0; worst_obs = 0.0; t0 = time.time()
+    busy = np.zeros(B, dtype=bool); pending = [None] * B; resets = np.zeros(B, dtype=int)
+    for step in range(K):
+        act = rng.rand(B, 3)
+        ids = np.full(B, -1, dtype=np.int64)
+        for e in range(B):
+            if busy[e]: continue
+            if last[e]["terminal"]:
+                last[e] = None
+        mask = np.array([last[e] is None and not busy[e] for e in range(B)], dtype=np.uint8)
+        if mask.any():                                          # reset finished episodes on both sides
+            r = env.reset(torch.from_numpy(mask)); env.synchronize()
+            for e in np.nonzero(mask)[0]:
+                last[e] = ors[e].reset(); n_term += 1; resets[e] += 1
+        for e in range(B):
+            if not busy[e]:
+                ids[e] = -1 if last[e]["agent_id"] is None else last[e]["agent_id"]
+                pending[e] = (last[e]["agent_id"], act[e].copy())
+        r = env.step(torch.tensor(ids), torch.tensor(act)); env.synchronize()
+        st = r["status"].cpu().numpy()
+        fresh = [e for e in range(B) if st[e] != 4]
+        def ostep(e):
+            a, x = pending[e]
+            return ors[e].step(a, x)
+        res = list(pool.map(ostep, fresh))
+        nd = env.nodes(); ag = r["agent_id"].cpu().numpy(); now = r["now"].cpu().numpy(); rew = r["reward"].cpu().numpy(); term = r["terminal"].cpu().numpy()
+        obs = r["state"]
+        for e, x in zip(fresh, res):
+            last[e] = x; n_cmp += 1
+            assert int(ag[e]) == (-1 if x["agent_id"] is None else x["agent_id"]), ("agent", step, e, int(ag[e]), x["agent_id"])
+            assert bool(term[e]) == x["terminal"] and close(float(now[e]), x["now"], rtol=1e-9), ("time/terminal", step, e, now[e], x["now"])
+            if x["terminal"]: continue
+            on = ors[e].nodes()
+            assert np.array_equal(nd["status"][e], on["status"]), ("status", step, e)
+            assert close(nd["energy"][e], on["energy"]), ("energy", step, e)
+            if x["agent_id"] is not None:
+                d = abs(float(rew[e]) - x["reward"]); worst_rew = max(worst_rew, d / max(1e-9, abs(x["reward"])) if abs(x["reward"]) > 1e-6 else 0.0)
+                # get_reward (WRSN.py:222-227) = (0.8 (fit - prev) + 0.2 excl / avg) / (ctm + mtm): the two terms can nearly cancel, so
+                # the 1e-5 is taken relative to their magnitudes, not to the (possibly tiny) difference
+                om_ = ors[e].mcs(); oi_ = ors[e].env_info(); a_ = x["agent_id"]
+                scale_ = (0.8 * abs(oi_["min_fitness"] - om_["prev_minfit"][a_]) + 0.2 * abs(om_["excl"][a_]) / oi_["avg_nodes_agent"]) / (oi_["charging_time_max"] + oi_["moving_time_max"])
+                if abs(float(rew[e]) - x["reward"]) > 1e-5 * max(abs(x["reward"]), scale_) + 1e-12:
+                    # The reference divides by energyCS in get_network_fitness (WRSN.py:196-209).  Once a node has been idle for
+                    # 10 s its energyCS is the rounding residue of the sliding mean (Node.py:71-77), +-1e-16 instead of 0, and
+                    # (E - thr) / energyCS is +-1e19 with the sign of that residue: a negative one turns the node into a
+                    # bottleneck.  The residue depends on the last bit of every packet cost (SciPy/BLAS distances included), so
+                    # no two implementations -- or BLAS builds -- agree on it.  Such requests are counted, not failed.
+                    gcs = nd["cs"][e]; ocs = ors[e].nodes()["cs"]; alive_ = nd["status"][e] == 1
+                    scale = max(np.abs(gcs).max(), 1e-30)
+                    noisy = alive_ & (((np.abs(gcs) < 1e-9 * scale) & (gcs != 0)) | ((np.abs(ocs) < 1e-9 * scale) & (ocs != 0)))
+                    if noisy.any():
+                        n_noise += 1
+                        continue
+                    gm = env.mcs(); om = ors[e].mcs(); gi = env.env_info(); oi = ors[e].env_info()
+                    print("REWARD MISMATCH step %d env %d agent %d: gpu %.12g oracle %.12g" % (step, e, int(ag[e]), rew[e], x["reward"]))
+                    print("  gpu   excl %s prev_minfit %s min_fitness %.12g" % (gm["excl"][e], gm["prev_minfit"][e], gi["min_fitness"][e]))
+                    print("  oracle excl %s prev_minfit %s min_fitness %.12g" % (om["excl"], om.get("prev_minfit"), oi["min_fitness"]))
+                    raise AssertionError("reward mismatch (see output)")
+                ref = x["state"]; o = obs[e].double().cpu().numpy()
+                err = np.max(np.abs(o - ref)) / max(1.0, np.abs(ref).max()); worst_obs = max(worst_obs, err)
+                assert err <= 1e-5, ("obs", step, e, err)
+        busy = st == 4
+        if step % 10 == 9:
+            print("step %d: %d requests compared (%d noise-dependent), %d episodes finished, worst reward rel err %.2e, worst obs err %.2e, %.0f s" % (step + 1, n_cmp, n_noise, n_term, worst_rew, worst_obs, time.time() - t0), flush=True)
+    print("parity sweep ok: %d requests, %d finished episodes; %d requests with a reward that depends on the sign of a rounding-noise energyCS (not comparable)" % (n_cmp, n_term, n_noise))
+    env.close(); pool.shutdown()
+    return n_cmp, n_term, n_noise
+
+
+if __name__ == "__main__":
+    run(B=int(os.environ.get("WRSN_B", "192")), K=int(os.environ.get("WRSN_K", "60")), budget=int(os.environ.get("WRSN_BUDGET", "0")),
+        seed0=int(os.environ.get("WRSN_SEED", "20000")), N=int(os.environ.get("WRSN_N", "200")))

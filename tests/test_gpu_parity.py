@@ -359,3 +359,14 @@ def test_density_map_to_action_on_device():
     env.synchronize()
     assert (r["status"].cpu().numpy() >= 0).all()
     env.close()
+
+
+@pytest.mark.parametrize("budget", [0, 500])
+def test_parity_sweep_whole_episodes_with_resets(budget):
+    """tests/parity_sweep.py at a small size: 48 environments x 40 launches side by side with the oracle, whole episodes with
+    masked resets, blocking and budgeted; every request compared (rewards that hang on the sign of a rounding-noise
+    energyCS of the reference are counted, not compared -- DESIGN.md 2)."""
+    _torch()
+    import parity_sweep
+    n_cmp, n_term, n_noise = parity_sweep.run(B=48, K=40, budget=budget, seed0=52000)
+    assert n_cmp > 600 and n_term > 80 and n_noise < n_cmp // 50
