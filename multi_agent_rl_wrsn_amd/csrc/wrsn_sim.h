@@ -821,7 +821,7 @@ struct Sim {
                 WRSN_PROF_MARK(x4_)
                 okr_ = walk_range(a, b, nbr, es, rrh, gain, margin);
                 WRSN_PROF_MARK(x5_)
-                if (rep_ == 0) { WRSN_PROF_SPAN(19, x4_, x5_) WRSN_PROF_CNT(20, 1) } else { WRSN_PROF_SPAN(22, x4_, x5_) }
+                (void)x4_; (void)x5_;
             }
 #else
             okr_ = walk_range(a, b, nbr, es, rrh, gain, margin);
@@ -1257,6 +1257,7 @@ struct Sim {
 #pragma unroll
         for (int j = 0; j < NPL; ++j) rrh[j] = any_rr ? SRR()[j * 64 + lane] * 0.5 : 0.0;
         for (long guard = 0; guard < 4000000L; ++guard) {
+            WRSN_PROF_MARK(lh0_)
             if (frozen) break;
             if (budget > 0 && work >= budget && guard > 0) break;   // out of budget: the next launch asks for this service again
             int k = 1; double bt = ur_time; int64_t bs = ur_seq;
@@ -1291,6 +1292,7 @@ struct Sim {
                     if (!fused) continue;
                 }
             }
+            WRSN_PROF_MARK(lh1_) WRSN_PROF_SPAN(22, lh0_, lh1_) WRSN_PROF_CNT(23, 1)
             if (!fused) {
                 // ---- one item (every O(N) routine has exactly one call site: the kernel has to fit the instruction cache)
                 WRSN_PROF_CNT(15, 1) work += 8;
@@ -1325,6 +1327,7 @@ struct Sim {
                 }
             }
             work += 4 * (nrep - q0);
+            WRSN_PROF_MARK(ps0_) WRSN_PROF_CNT(20, nrep - q0)
             for (int q = q0; q < nrep; ++q) {
                 if (fused) {
                     if (any_rr) {
@@ -1341,6 +1344,7 @@ struct Sim {
                     for (int j = 0; j < NPL; ++j) { const double e = fmin(E[j] + rrh[j], cap); E[j] = ((am >> j) & 1u) ? e : E[j]; }
                 }
             }
+            WRSN_PROF_MARK(ps1_) WRSN_PROF_SPAN(19, ps0_, ps1_)
             if (fused) continue;
             if (one || deaths_flag) break;
         }

@@ -8,7 +8,7 @@ _lib._lib = _lib.bind(C.CDLL(os.path.join(ROOT, "tools", "libwrsn_hip_profile.so
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 NAMES = ["scalar_run", "grid_run", "steady_batch", "update_reward", "exact_walk", "rebuild_cache", "set_levels", "min_fitness",
          "generic_items(incl)", "ur_flush", "load", "store", "#services", "#fused_s", "#jumped_s", "#generic_items",
-         "xw:receivers", "xw:single", "#single", "xw:range", "#range", "#locate", "xw:range_again(warm)", "#range_again"]
+         "xw:receivers", "xw:single", "#single", "grid:per_second_loop", "#per_second_s", "#locate", "grid:loop_head", "#grid_iterations"]
 def prof(env):
     a = np.zeros((env.num_env * 25,), dtype=np.int64)
     _lib.check(env._h.lib, env._h.lib.wrsn_peek(env._h._h, 10, a.ctypes.data))
