@@ -121,12 +121,13 @@ int wrsn_set_scenario(wrsn_t *h, int32_t env0, int32_t nenv,
                       const wrsn_mc_spec *mc_spec, int32_t mc_spec_stride);
 
 /* WRSN.reset (WRSN.py:41-83) for the environments whose env_mask byte is non-zero
- * (DEVICE pointer [B]; NULL = all).  Outputs follow the reset request (agent 0, reward 0). */
+ * (DEVICE pointer [B]; NULL = all).  Outputs follow the reset request (agent 0, reward 0).  Rows of environments
+ * the mask leaves out are not written at all: their pending request (agent_id included) stays valid. */
 int wrsn_reset(wrsn_t *h, const uint8_t *env_mask, const wrsn_step_out *out);
 
 /* WRSN.step (WRSN.py:289-330) for every environment, density_map=False path.
  *   agent_id [B] DEVICE int32: charger receiving `action` (>= 0), -1 = "just run" (WRSN.py:290),
- *                              -2 = leave this environment untouched;
+ *                              -2 = leave this environment untouched (none of its output rows is written);
  *   action   [B,3] DEVICE double: normalised action, clipped to [0,1] inside (WRSN.py:299).
  * auto_reset != 0: an environment whose previous return was terminal is reset instead of stepped
  * and reports status 3 with the reset request (agent 0, reward 0). */

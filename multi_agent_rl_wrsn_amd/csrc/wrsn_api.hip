@@ -26,6 +26,21 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (e_ != hipSuccess) return fail(WRSN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point runs on the handle's device and leaves the calling thread's current device as it found it (handles of
+// different GPUs may share a process and a thread with torch).
+struct DeviceGuard {
+    int prev; bool ok;
+    explicit DeviceGuard(int dev) : prev(-1), ok(false) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) prev = -1;                            // nothing to restore
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define WRSN_ON_DEVICE(h_)                                                                             \
+    DeviceGuard guard_((h_)->cfg.device);                                                              \
+    if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed for the handle's device")
+
 int npl_for(int n_node) {
     int need = (n_node + 63) / 64;
     const int choices[] = {1, 2, 4, 8, 16};
@@ -43,11 +58,9 @@ struct wrsn_handle {
     int scenario_set;
     int lds_env, lds_obs;
     int slots;                 // wave slots of the device for the step kernel (CUs x 8): launch-order dependent budgets
-    int epoch;                 // launch counter of wrsn_step (parity selects the in-flight list)
+    long long epoch;           // launch counter of budgeted wrsn_step calls (epoch % 3 selects the in-flight list)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     std::vector<void*> allocs;
-    int32_t* d_agent_tmp;      // [B] agent ids for rendering when the caller passes no agent_id output
-    int32_t* d_reset_agent;    // [B] -1 everywhere: "agent" argument of a reset launch
     WrsnDev* d_dev;            // device copy of `dev`: the environment kernels read it through the constant cache
 };
 
@@ -89,11 +102,8 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
     dim3 grid(budget > 0 ? 2 * nenv : nenv), block(64);
-    int epoch = 0;
-    if (budget > 0) {                                          // the list this launch fills must start empty
-        epoch = ++h->epoch;
-        HIPCHK(hipMemsetAsync(h->dev.prio_n + ((epoch + 1) & 1), 0, sizeof(int32_t), h->stream));
-    }
+    long long epoch = 0;
+    if (budget > 0) epoch = ++h->epoch;                        // the kernel itself empties the list the launch after it fills
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else hipLaunchKernelGGL(wrsn_step_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
@@ -155,7 +165,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(WRSN_ERR_NO_DEVICE, "no HIP device: libwrsn_hip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(WRSN_ERR_ARG, "device ordinal out of range");
-    HIPCHK(hipSetDevice(cfg->device));
+    DeviceGuard guard_(cfg->device);
+    if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
     h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1;
     { hipDeviceProp_t pr; h->slots = (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount * 8 : 2048; }
@@ -199,17 +210,12 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = alloc_node_arrays(h, &d.live))) break;
         if ((rc = alloc_node_arrays(h, &d.snap))) break;
         if ((rc = dalloc(h, &d.counters, B * 25))) break;
-        if ((rc = dalloc(h, &d.prio_list, 2 * B))) break;
-        if ((rc = dalloc(h, &d.prio_n, 2))) break;
-        if ((rc = dalloc(h, &h->d_agent_tmp, B))) break;
-        if ((rc = dalloc(h, &h->d_reset_agent, B))) break;
+        if ((rc = dalloc(h, &d.prio_list, 3 * B))) break;
+        if ((rc = dalloc(h, &d.prio_n, 3))) break;
+        if ((rc = dalloc(h, &d.render_agent, B))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
     } while (0);
     if (rc) { wrsn_destroy(h); return rc; }
-    {
-        std::vector<int32_t> neg(B, -1);
-        if (hipMemcpy(h->d_reset_agent, neg.data(), B * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
-    }
     if (hipMemcpy(h->d_dev, &h->dev, sizeof(WrsnDev), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
     *out = h;
     return WRSN_OK;
@@ -217,7 +223,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
 
 void wrsn_destroy(wrsn_t* h) {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceGuard guard_(h->cfg.device);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -235,7 +241,7 @@ int wrsn_set_scenario(wrsn_t* h, int32_t env0, int32_t nenv, const double* node_
     if (!h || !node_xy || !target_xy || !bs_xy || !node_spec || !mc_spec) return fail(WRSN_ERR_ARG, "null argument");
     const WrsnDev& d = h->dev;
     if (env0 < 0 || nenv < 1 || env0 + nenv > d.B) return fail(WRSN_ERR_ARG, "environment range out of bounds");
-    HIPCHK(hipSetDevice(h->cfg.device));
+    WRSN_ON_DEVICE(h);
     const size_t NP = d.NP, TP = d.TP;
     std::vector<double> hx(nenv * NP, 0.0), hy(nenv * NP, 0.0), tx(nenv * TP, 0.0), ty(nenv * TP, 0.0);
     std::vector<WrsnEnvConst> ec(nenv);
@@ -281,35 +287,37 @@ int wrsn_set_scenario(wrsn_t* h, int32_t env0, int32_t nenv, const double* node_
 int wrsn_reset(wrsn_t* h, const uint8_t* env_mask, const wrsn_step_out* out) {
     if (!h || !out) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
-    WrsnStepOutDev o; o.agent_id = out->agent_id ? out->agent_id : h->d_agent_tmp; o.reward = out->reward; o.terminal = out->terminal;
+    WRSN_ON_DEVICE(h);
+    // rows of environments the mask leaves out keep every output, agent_id included; what the render pass draws comes
+    // from the list the environment kernel writes (WrsnDev.render_agent), not from the caller's agent_id array
+    WrsnStepOutDev o; o.agent_id = out->agent_id; o.reward = out->reward; o.terminal = out->terminal;
     o.now = out->now; o.obs = out->obs; o.status = out->status;
-    if (env_mask && out->obs) {
-        // rows of unmasked environments must not be rendered: mark them with agent -1 first
-        HIPCHK(hipMemcpyAsync(o.agent_id, h->d_reset_agent, (size_t)h->dev.B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
-    }
     int rc = launch_env(h, WRSN_MODE_RESET, 0, h->dev.B, nullptr, nullptr, 0, env_mask, o);
     if (rc) return rc;
-    if (out->obs) return launch_obs(h, o.agent_id, out->obs);
+    if (out->obs) return launch_obs(h, h->dev.render_agent, out->obs);
     return WRSN_OK;
 }
 
 int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t auto_reset, const wrsn_step_out* out) {
     if (!h || !out || !agent_id || !action) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
-    WrsnStepOutDev o; o.agent_id = out->agent_id ? out->agent_id : h->d_agent_tmp; o.reward = out->reward; o.terminal = out->terminal;
+    WRSN_ON_DEVICE(h);
+    // rows with agent_id -2 keep every output (their pending request included)
+    WrsnStepOutDev o; o.agent_id = out->agent_id; o.reward = out->reward; o.terminal = out->terminal;
     o.now = out->now; o.obs = out->obs; o.status = out->status;
-    if (out->obs) HIPCHK(hipMemcpyAsync(o.agent_id, h->d_reset_agent, (size_t)h->dev.B * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
     int rc = launch_env(h, WRSN_MODE_STEP, 0, h->dev.B, agent_id, action, auto_reset, nullptr, o);
     if (rc) return rc;
-    if (out->obs) return launch_obs(h, o.agent_id, out->obs);
+    if (out->obs) return launch_obs(h, h->dev.render_agent, out->obs);
     return WRSN_OK;
 }
 
 int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     if (!h || work_units < 0) return fail(WRSN_ERR_ARG, "bad step budget");
+    WRSN_ON_DEVICE(h);
     if ((work_units > 0) != (h->step_budget > 0)) {            // (re)entering budgeted mode: no environment is listed yet
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemset(h->dev.prio_n, 0, 2 * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->dev.prio_n, 0, 3 * sizeof(int32_t)));
+        h->epoch += 4;                                         // stamps left by earlier budgeted launches name no future launch
     }
     h->step_budget = work_units;
     return WRSN_OK;
@@ -318,6 +326,7 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
 int wrsn_density_action(wrsn_t* h, const int32_t* agent_id, const double* dmap, double* action) {
     if (!h || !agent_id || !dmap || !action) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    WRSN_ON_DEVICE(h);
     // np.percentile(map, 99.9), method "linear": virtual index (n - 1) q, the two order statistics around it and the weight
     const int n = h->dev.G * h->dev.G;
     const double q = 99.9 / 100.0, vi = (double)(n - 1) * q, lo = std::floor(vi);
@@ -332,6 +341,7 @@ int wrsn_density_action(wrsn_t* h, const int32_t* agent_id, const double* dmap, 
 int wrsn_rollout_table(wrsn_t* h, double* dst, int32_t zero_after) {
     if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    WRSN_ON_DEVICE(h);
     hipLaunchKernelGGL(wrsn_rollout_kernel, dim3((h->dev.B + 255) / 256), dim3(256), 0, h->stream, h->dev, dst, (int)zero_after);
     HIPCHK(hipGetLastError());
     return WRSN_OK;
@@ -340,11 +350,13 @@ int wrsn_rollout_table(wrsn_t* h, double* dst, int32_t zero_after) {
 int wrsn_render(wrsn_t* h, const int32_t* agent_id, float* obs) {
     if (!h || !agent_id || !obs) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
+    WRSN_ON_DEVICE(h);
     return launch_obs(h, agent_id, obs);
 }
 
 int wrsn_sync(wrsn_t* h) {
     if (!h) return fail(WRSN_ERR_ARG, "null handle");
+    WRSN_ON_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     return WRSN_OK;
 }
@@ -353,7 +365,7 @@ int wrsn_peek(wrsn_t* h, int32_t what, void* dst) {
     if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
     const WrsnDev& d = h->dev;
     const size_t B = d.B, NP = d.NP, N = d.N;
-    HIPCHK(hipSetDevice(h->cfg.device));
+    WRSN_ON_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     auto node_f64 = [&](const double* src) -> int {
         std::vector<double> tmp(B * NP);
@@ -422,7 +434,7 @@ int wrsn_peek(wrsn_t* h, int32_t what, void* dst) {
 int wrsn_counters(wrsn_t* h, int64_t* dst) {
     if (!h || !dst) return fail(WRSN_ERR_ARG, "null argument");
     const size_t B = h->dev.B;
-    HIPCHK(hipSetDevice(h->cfg.device));
+    WRSN_ON_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<WrsnEnvDyn> dy(B);
     HIPCHK(hipMemcpy(dy.data(), h->dev.live.dyn, B * sizeof(WrsnEnvDyn), hipMemcpyDeviceToHost));

@@ -599,7 +599,8 @@ struct Sim {
     // pay (Node.py:116-117, 126-127), which re-routes everything behind it.  As long as nobody can fail, the order inside a
     // range of sources does not matter, so the second is replayed range by range in closed form (bisection down to one
     // source) and only the single source whose packets may hit a starving node is walked packet by packet on lane 0.
-    struct WalkRec { double E; int32_t rcv; float es; };      // LDS record for the packet-by-packet walk
+    // LDS records of the packet-by-packet walk: energy and send cost in float64 (SU()[0..NP), SU()[NP..2NP)), receiver in
+    // the float-CS array of the steady batch, which is idle here
 
     // receivers + send cost of every alive node for the current (live status, last levels); returns max op cost
     WDEV double walk_receivers(const NbRegs& nbr, double (&es)[NPL]) {
@@ -727,15 +728,14 @@ struct Sim {
     // death and reports where to go on (SREQ()[3] = next packet, SREQ()[0] = packets of the source); the caller re-routes
     // with the whole wave and calls again.
     WDEV int walk_single(int q, int p0, double (&es)[NPL], const double (&rrh)[NPL], double (&gain)[NPL]) {
-        WalkRec* rec = (WalkRec*)SU();
+        double* recE = SU(); double* recS = SU() + NP; int32_t* recR = (int32_t*)SCSF();
         const double er = EC()->e_recv;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane;
             if (p0 == 0 && i == q && ((am >> j) & 1u)) { double e2 = fmin(E[j] + rrh[j], cap); gain[j] += e2 - E[j]; E[j] = e2; }   // the source wakes
-            WalkRec w; w.E = E[j]; w.rcv = SRCV()[i]; w.es = (float)es[j];
-            rec[i] = w;
+            recE[i] = E[j]; recS[i] = es[j]; recR[i] = SRCV()[i];
         }
         __syncthreads();
         if (lane == 0) {
@@ -745,17 +745,16 @@ struct Sim {
                 for (; p < nc && deaths == 0; ++p) {
                     int cur = q;
                     for (int hop = 0; hop <= N; ++hop) {
-                        WalkRec w = rec[cur];
-                        const int r = w.rcv; const double esv = (double)w.es;
-                        if (r == -1) { if (w.E <= thr) { SLS()[cur] &= ~1; deaths++; } break; }
-                        if (w.E - thr < esv) { rec[cur].E = thr; SLS()[cur] &= ~1; deaths++; break; }
-                        double e = w.E - esv;
-                        rec[cur].E = e;
+                        const double wE = recE[cur], esv = recS[cur]; const int r = recR[cur];
+                        if (r == -1) { if (wE <= thr) { SLS()[cur] &= ~1; deaths++; } break; }
+                        if (wE - thr < esv) { recE[cur] = thr; SLS()[cur] &= ~1; deaths++; break; }
+                        double e = wE - esv;
+                        recE[cur] = e;
                         if (e <= thr) { SLS()[cur] &= ~1; deaths++; }
                         if (r == -2) break;
-                        double e_r = rec[r].E;
-                        if (e_r - thr < er) { rec[r].E = thr; SLS()[r] &= ~1; deaths++; break; }
-                        rec[r].E = e_r - er;
+                        double e_r = recE[r];
+                        if (e_r - thr < er) { recE[r] = thr; SLS()[r] &= ~1; deaths++; break; }
+                        recE[r] = e_r - er;
                         cur = r;
                     }
                 }
@@ -765,7 +764,7 @@ struct Sim {
         __syncthreads();
         const int deaths = SREQ()[1];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) E[j] = rec[j * 64 + lane].E;
+        for (int j = 0; j < NPL; ++j) E[j] = recE[j * 64 + lane];
         __syncthreads();
         return deaths;
     }
@@ -1783,7 +1782,7 @@ struct Sim {
     WDEV bool run(bool use_limit, double limit, int budget_ = 0) {
         double svc = 0.0;
         work = 0; budget = budget_;
-        bool suspended = false;
+        bool suspended = false, stopped = false;
         for (long guard = 0; guard < 8000000L; ++guard) {
             { WRSN_PROF_T0
             if (lane == 0) {
@@ -1795,7 +1794,7 @@ struct Sim {
             WRSN_PROF_ADD(0) WRSN_PROF_CNT(12, 1) }
             const int req = SREQ()[0], arg = SREQ()[1];
             now = wu(SREQD()[1]); seq = wu(((const int64_t*)SREQD())[2]);      // lane 0 advanced them while firing events
-            if (req == REQ_STOP) break;
+            if (req == REQ_STOP) { stopped = true; break; }
             work += 16;
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
@@ -1806,6 +1805,7 @@ struct Sim {
             }
             __syncthreads();
         }
+        if (!stopped && !suspended) err = -10;               // the service loop ran out: the environment is stuck, report it (status < 0)
         __syncthreads();
         if (lane == 0 && !suspended) ff_sync_all(now);       // bring virtual charger sub-steps up to the return instant
         __syncthreads();
@@ -1888,25 +1888,31 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
 
 template <int NPL>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
-                                                       const double* __restrict__ action, int auto_reset, int budget, int epoch, int slots,
+                                                       const double* __restrict__ action, int auto_reset, int budget, long long epoch, int slots,
                                                        const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     // With a step budget the grid is 2 B blocks: the first B take the environments whose step is in flight (the long
-    // jobs of this launch, listed by the previous one) so that they start first; block B + e takes environment e
-    // unless it is in flight or was already handled in this launch.
+    // jobs of this launch, listed by the previous one) so that they start first; block B + r takes one of the others.
+    // Who owns an environment is decided from `listed_for` alone, a stamp written where a step suspends -- by the launch
+    // BEFORE this one for every environment this launch has listed -- or zeroed by a reset launch: a listed block owns
+    // its environment iff the stamp names this launch, block B + r owns its environment iff the stamp is older.  The
+    // only write during the launch is the owner's own (stamp = next launch, when its step suspends again), and that
+    // value still tells block B + r to keep out; nothing the owner stores while it finishes is looked at by the other.
     int env = blockIdx.x; bool listed = false;
+    const int cur_l = (int)(epoch % 3), next_l = (int)((epoch + 1) % 3);
     if (budget > 0 && !reset_call) {
+        if (blockIdx.x == 0 && lane == 0) dp->prio_n[(int)((epoch + 2) % 3)] = 0;   // the list the next launch fills (last read two launches ago)
         if ((int)blockIdx.x < dp->B) {
-            if ((int)blockIdx.x >= dp->prio_n[epoch & 1]) return;
-            env = dp->prio_list[(size_t)(epoch & 1) * dp->B + blockIdx.x]; listed = true;
+            if ((int)blockIdx.x >= dp->prio_n[cur_l]) return;
+            env = dp->prio_list[(size_t)cur_l * dp->B + blockIdx.x]; listed = true;
         } else {
             // blocks are dispatched in index order: a block far behind the first `slots` ones starts late, and what it is
             // allowed to spend shrinks accordingly so that the launch does not wait for late long jobs.  The mapping
             // block -> environment rotates with the launch number, so no environment is always last.
             const int r = blockIdx.x - dp->B;
-            env = (int)(((long long)r + (long long)epoch * 1031) % dp->B);
-            const int k = dp->prio_n[epoch & 1] + r - slots;
+            env = (int)(((long long)r + (epoch % dp->B) * 1031) % dp->B);
+            const int k = dp->prio_n[cur_l] + r - slots;
 #ifndef WRSN_BUDGET_SLOPE
 #define WRSN_BUDGET_SLOPE 2
 #define WRSN_BUDGET_FLOOR 4
@@ -1914,23 +1920,28 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (k > 0) { const int cut = (int)((long long)budget * k / (WRSN_BUDGET_SLOPE * slots)); budget = (budget - cut > budget / WRSN_BUDGET_FLOOR) ? budget - cut : budget / WRSN_BUDGET_FLOOR; }
         }
     }
-    if (env >= dp->B) return;
+    if (env < 0 || env >= dp->B) return;
     bool do_reset = reset_call != 0;
-    if (reset_call && env_mask && env_mask[env] == 0) return;
+    // a row nobody handles in this launch is not rendered and none of its outputs is touched
+    if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) dp->render_agent[env] = -1; return; }
     int aid = -1, resume = 0;
     if (!reset_call) {
         aid = agent_id[env];
-        resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (budget > 0) {
+            const long long stamp = dp->live.dyn[env].listed_for;
             if (listed) {
-                if (!resume) return;                       // reset in the meantime: block B + env handles it
+                if (stamp != epoch) return;                // reset since it was listed: block B + r owns it
                 if (aid == -2) {                           // left untouched: stays in flight, stays listed
-                    if (lane == 0) { const int pos = atomicAdd(&dp->prio_n[(epoch + 1) & 1], 1); dp->prio_list[(size_t)((epoch + 1) & 1) * dp->B + pos] = env; }
+                    if (lane == 0) {
+                        const int pos = atomicAdd(&dp->prio_n[next_l], 1); dp->prio_list[(size_t)next_l * dp->B + pos] = env;
+                        dp->live.dyn[env].listed_for = epoch + 1; dp->render_agent[env] = -1;
+                    }
                     return;
                 }
-            } else if (resume || dp->live.dyn[env].epoch == epoch) return;
+            } else if (stamp >= epoch) return;             // listed for this launch: the listed block owns it
         }
-        if (aid == -2) return;
+        if (aid == -2) { if (lane == 0) dp->render_agent[env] = -1; return; }
+        resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
     Sim<NPL> s;
@@ -1956,6 +1967,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = (s.alive == 1) ? 0 : 1;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = reset_call ? 0 : 3;
+            dp->render_agent[env] = agent;
         }
     } else {
         // ------------------------------------------------------ WRSN.step
@@ -2010,8 +2022,12 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = 0;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
-            const int pos = atomicAdd(&dp->prio_n[(epoch + 1) & 1], 1);      // first in line in the next launch
-            dp->prio_list[(size_t)((epoch + 1) & 1) * dp->B + pos] = env;
+            dp->render_agent[env] = -1;
+            if (budget > 0) {                                // first in line in the next launch
+                const int pos = atomicAdd(&dp->prio_n[next_l], 1);
+                dp->prio_list[(size_t)next_l * dp->B + pos] = env;
+                dy->listed_for = epoch + 1;
+            }
         }
         if (lane == 0 && !susp) {
             int agent = -1, status = st0; double reward = 0.0;
@@ -2035,10 +2051,11 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = (uint8_t)terminal;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = status;
+            dp->render_agent[env] = agent;
         }
     }
     s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp);
-    if (lane == 0 && !reset_call) dp->live.dyn[env].epoch = epoch;
+    if (lane == 0 && reset_call) dp->live.dyn[env].listed_for = 0;   // a reset launch takes the environment off the in-flight list
 #ifdef WRSN_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
 #if WRSN_PROFILE >= 3

@@ -55,7 +55,8 @@ struct WrsnEnvDyn {
     int32_t net_phase, net_active, node_phase, alive;
     int32_t levels_dirty, cache_dirty, irreg, ring_len;
     int32_t ring_head, safe_ticks, frozen, terminal_pending;
-    int32_t epoch, pad2;                     // launch that handled this environment last (step budget)
+    int64_t listed_for;                      // step budget: launch whose in-flight list holds this environment (written where a step
+                                             // suspends, i.e. by the launch before; 0 after a reset)
     int32_t n_connected, error, log_pending, susp;   // susp: WRSN.step in flight (work budget of a launch used up)
     // the `|` conditions of the step in flight (WRSN.py:307-311); only meaningful while susp != 0
     double cond_time[WRSN_MAX_MC + 1]; int64_t cond_seq[WRSN_MAX_MC + 1];
@@ -96,8 +97,11 @@ struct WrsnDev {
     uint32_t *tcp;                    // [B][TP][4]  the first eight covering node ids of a target, packed alike
     WrsnNodeArrays live, snap;        // current state / post-warm-up snapshot
     int64_t *counters;                // [4]
-    int32_t *prio_list;               // [2][B] environments whose step is in flight (step budget), one list per launch parity
-    int32_t *prio_n;                  // [2]    their counts
+    int32_t *prio_list;               // [3][B] environments whose step is in flight (step budget): launch e reads list e % 3, fills
+                                      //        list (e + 1) % 3 and empties the count of list (e + 2) % 3 for the launch after it
+    int32_t *prio_n;                  // [3]    their counts
+    int32_t *render_agent;            // [B]    charger whose observation the launch's render pass draws (-1: none); written by the
+                                      //        environment kernel for every row, including the rows it leaves untouched
 };
 
 struct WrsnStepOutDev {

@@ -35,6 +35,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorUnknown; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
@@ -143,10 +144,12 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline float __expf(float x) { return expf(x); }
 
+extern int emu_block_order;                  // 0: blocks run in index order, 1: in reverse order (HIP promises no order)
 template <typename K, typename... A>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*lds*/, hipStream_t, A... args) {
     gridDim.x = grid.x; blockDim.x = block.x;
-    for (unsigned b = 0; b < grid.x; ++b) {
+    for (unsigned b_ = 0; b_ < grid.x; ++b_) {
+        const unsigned b = emu_block_order == 1 ? grid.x - 1 - b_ : b_;
         blockIdx.x = b;
         emu_run_block([&]() { kernel(args...); }, block.x);
     }

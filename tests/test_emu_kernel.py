@@ -273,3 +273,86 @@ def test_emulated_step_budget_untouched_and_reset_rows():
         ids[3] = -1
         ev.step(ids, np.zeros((4, 3)), with_obs=False)
     assert ev.status[3] != 4 and ev.agent_id[3] == want[0][3] and ev.now[3] == want[1][3]
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_emulated_step_budget_handles_every_environment_once_per_launch(order):
+    """Ownership of an environment inside a budgeted launch (2 B blocks: listed in-flight environments first, everybody
+    else behind): whatever order the blocks run in, an environment executes at most one WRSN.step per launch, the rollout
+    table equals the host-side accumulation of the returned requests, and the requests equal the blocking run's."""
+    from emu_env import emu_lib
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    B, M, K = 5, 2, 30
+    scs = [synth_scenario(80 + e, 70, 60) for e in range(B)]
+    rng = np.random.RandomState(9)
+    acts = rng.rand(K, B, 3)
+
+    def run(budget):
+        ev = _emu(scs, DEFAULT_MC_SPEC, M)
+        if budget: ev.h.set_step_budget(budget)
+        ev.reset(with_obs=False)
+        tab = np.zeros((B, M + 3)); want = np.zeros((B, M + 3)); hist = [[] for _ in range(B)]
+        nxt = np.zeros(B, dtype=int); busy = np.zeros(B, dtype=bool); done = np.zeros(B, dtype=bool)
+        cur = ev.agent_id.copy()
+        for it in range(4000):
+            if done.all(): break
+            ids = cur.copy(); ids[done] = -2
+            act = np.stack([acts[min(nxt[e], K - 1), e] for e in range(B)])
+            before = (ev.agent_id.copy(), ev.reward.copy(), ev.now.copy())
+            ev.step(ids, act, with_obs=False)
+            ev.h.rollout_table(tab.ctypes.data, True)
+            assert tab[:, M + 2].max() <= 1.0                 # never two WRSN.step calls of one environment in a launch
+            for e in range(B):
+                if done[e]:                                   # untouched row: every output keeps its value
+                    assert tab[e].sum() == 0 and ev.agent_id[e] == before[0][e] and ev.reward[e] == before[1][e] and ev.now[e] == before[2][e]
+                    continue
+                if not busy[e]: nxt[e] += 1
+                if ev.status[e] == 4:
+                    busy[e] = True; assert tab[e].sum() == 0
+                    continue
+                busy[e] = False
+                assert tab[e, M + 2] == 1.0
+                if ev.agent_id[e] >= 0: want[e, ev.agent_id[e]] = ev.reward[e]
+                want[e, M] = float(ev.terminal[e]); want[e, M + 1] = ev.now[e] if ev.terminal[e] else 0.0; want[e, M + 2] = 1.0
+                assert np.allclose(tab[e], want[e], rtol=1e-12, atol=0); want[e] = 0
+                hist[e].append((int(ev.agent_id[e]), float(ev.now[e]), float(ev.reward[e]), int(ev.terminal[e])))
+                if ev.terminal[e] or ev.agent_id[e] < 0 or nxt[e] >= K: done[e] = True
+            cur = ev.agent_id.copy()
+        assert done.all()
+        return hist
+
+    lib = emu_lib()
+    ref = run(0)
+    lib.emu_set_block_order(order)
+    try:
+        got = run(30)
+    finally:
+        lib.emu_set_block_order(0)
+    for e in range(B):
+        assert len(got[e]) == len(ref[e])
+        for a, b in zip(ref[e], got[e]):
+            assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3] and abs(a[2] - b[2]) <= 1e-7 * max(1.0, abs(a[2])), (e, a, b)
+
+
+def test_emulated_untouched_and_unmasked_rows_keep_their_request():
+    """agent_id -2 in step() and a zero mask byte in reset(mask) leave a row's outputs alone -- the pending request id
+    included -- so `r = reset(mask); step(r.agent_id, a)` is safe for the environments that were not reset."""
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    scs = [synth_scenario(90 + e, 70, 60) for e in range(3)]
+    ev = _emu(scs, DEFAULT_MC_SPEC, 2)
+    ev.reset()
+    rng = np.random.RandomState(1)
+    for _ in range(3):
+        ev.step(ev.agent_id.copy(), rng.rand(3, 3))
+    keep = (ev.agent_id.copy(), ev.reward.copy(), ev.now.copy(), ev.terminal.copy(), ev.status.copy(), ev.obs.copy())
+    assert (keep[0] >= 0).all()
+    mask = np.array([0, 1, 0], dtype=np.uint8)
+    ev.h.reset(mask.ctypes.data, **ev._ptrs(True))
+    for e in (0, 2):
+        assert ev.agent_id[e] == keep[0][e] and ev.reward[e] == keep[1][e] and ev.now[e] == keep[2][e] and np.array_equal(ev.obs[e], keep[5][e])
+    assert ev.agent_id[1] == 0 and ev.now[1] == 100.0 and ev.reward[1] == 0.0
+    keep1 = (ev.agent_id.copy(), ev.reward.copy(), ev.now.copy(), ev.obs.copy())
+    ids = np.array([-2, int(ev.agent_id[1]), -2], dtype=np.int32)
+    ev.step(ids, rng.rand(3, 3))
+    for e in (0, 2):
+        assert ev.agent_id[e] == keep1[0][e] and ev.reward[e] == keep1[1][e] and ev.now[e] == keep1[2][e] and np.array_equal(ev.obs[e], keep1[3][e])
