@@ -12,6 +12,15 @@ The same workload with blocking steps (budget 0, every launch waits for its slow
 reported under "blocking".
 Environments are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is
 one all-gather of the rollout returns table after the timed region.
+
+`--gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this process starts N rank processes of itself -- before it
+touches torch or the GPU -- with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR 127.0.0.1),
+forwards rank 0's JSON line and exits with the worst return code.  The line carries `ranks`, the size of the RCCL
+group the ranks really formed (counted with an all-reduce), next to `n_gpus`.
+
+Next to env-steps/s the line reports `sim_ticks_per_s` (simulated seconds x environments per wall
+second), `mean_ticks_per_env_step` and `zero_time_step_share` (completed WRSN.step calls that returned at the instant
+they were called: the bookkeeping returns at t = 100 after every reset).
 """
 import argparse
 import json
@@ -92,7 +101,8 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
         dist.barrier()
     elapsed = time.perf_counter() - t0
     c1 = env.counters()
-    res = {"elapsed": elapsed, "env_steps": c1["env_steps"] - c0["env_steps"], "ticks": c1["ticks"], "exact_ticks": c1["exact_ticks"],
+    res = {"elapsed": elapsed, "env_steps": c1["env_steps"] - c0["env_steps"], "sim_seconds": c1["sim_seconds_total"] - c0["sim_seconds_total"],
+           "zero_steps": c1["zero_time_steps"] - c0["zero_time_steps"], "exact_ticks": c1["exact_ticks"],
            "table": RolloutStats.gather_table(env.rollout_table()), "t_set": t_set}   # the path's one exchange step (RCCL all-gather)
 
     # ---- per-kernel timing pass (HIP events on the stream the kernels are launched on) ----------------------
@@ -120,6 +130,24 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, before this process touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,15 +166,24 @@ def main():
                          "launch waits for its slowest WRSN.step")
     ap.add_argument("--no-blocking-run", action="store_true", help="skip the additional blocking-mode (step_budget 0) measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                                  # never returns
 
     import torch
     from multi_agent_rl_wrsn_amd import init_distributed, synth_scenario
     rank, world, local_rank = init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = torch.distributed if world > 1 else None
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    ranks = 1
+    if dist:                                                   # how many ranks the RCCL group really has
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)
+        ranks = int(one[0])
+        if ranks != args.gpus or dist.get_backend() != "nccl":
+            raise SystemExit("process group has %d ranks on backend %s, expected %d on nccl" % (ranks, dist.get_backend(), args.gpus))
 
     B, N, T, M, G = args.envs, args.nodes, args.targets, args.mcs, args.map_size
     t_gen = time.time()
@@ -156,10 +193,11 @@ def main():
 
     def reduced(res):
         el = torch.tensor([res["elapsed"]], dtype=torch.float64, device=dev)
-        cnt = torch.tensor([res["env_steps"]], dtype=torch.float64, device=dev)
+        cnt = torch.tensor([res["env_steps"], res["sim_seconds"], res["zero_steps"]], dtype=torch.float64, device=dev)
         if dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)           # slowest rank
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)          # whole job
+        res["sim_seconds_all"], res["zero_steps_all"] = float(cnt[1]), float(cnt[2])
         return float(el[0]), float(cnt[0])
 
     main_res = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, args.step_budget, args.steps, args.warmup, args.kernel_steps)
@@ -170,6 +208,8 @@ def main():
         bres = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, 0, bsteps, max(5, args.warmup // 2), max(2, args.kernel_steps // 2))
         bel, bcnt = reduced(bres)
         blocking = {"value": bcnt / bel, "unit": "env-steps/s", "steps": bsteps, "ms_per_step": 1e3 * bel / bsteps,
+                    "sim_ticks_per_s": bres["sim_seconds_all"] / bel, "mean_ticks_per_env_step": bres["sim_seconds_all"] / max(1.0, bcnt),
+                    "zero_time_step_share": bres["zero_steps_all"] / max(1.0, bcnt),
                     "kernels": {"wrsn_step_kernel_ms": 1e3 * bres["env_launch"], "wrsn_obs_kernel_ms": 1e3 * bres["obs_launch"],
                                 "env_steps_per_launch": bres["units"]},
                     "note": "step_budget 0: every launch runs each WRSN.step to its end and waits for the slowest environment"}
@@ -182,11 +222,16 @@ def main():
         dom, dur, per_unit = "wrsn_obs_kernel", obs_launch, obs_b
     achieved = per_unit * units / dur / 1e9
     peak = 8000.0
-    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or null
-    traffic = None
+    # HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (profiles/), attached
+    # only when they were taken on THIS configuration (the file names it); null otherwise
+    traffic = None; traffic_src = None
+    this_cfg = {"envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "step_budget": args.step_budget}
     try:
-        tfile = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))[-1]
-        traffic = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"][dom]["hbm_bytes_per_launch"]
+        for tfile in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+            tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
+            if tj.get("config") == this_cfg and dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]; traffic_src = "profiles/" + tfile
+                break
     except Exception:
         traffic = None
 
@@ -194,18 +239,21 @@ def main():
         value = env_steps / elapsed
         out = {
             "metric": "env-steps/sec (whole node), 4096 envs x 200 nodes, 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "ranks": ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 (physics) / f32 (observation)", "data": "synthetic",
             "config": {"workload": "%d envs/GPU x %d nodes x %d targets x %d MC, random policy U[0,1)^3, auto-reset, 4x%dx%d observation" % (B, N, T, M, G, G),
                        "step_budget": args.step_budget, "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G,
                        "parallelism": "env-shard x%d" % world},
-            "env_steps_timed": env_steps, "mean_episode_seconds_so_far": main_res["mean_episode_seconds"],
+            "env_steps_timed": env_steps, "sim_ticks_per_s": main_res["sim_seconds_all"] / elapsed,
+            "mean_ticks_per_env_step": main_res["sim_seconds_all"] / max(1.0, env_steps),
+            "zero_time_step_share": main_res["zero_steps_all"] / max(1.0, env_steps),
+            "mean_episode_seconds_so_far": main_res["mean_episode_seconds"],
             "mean_return_table_rows": int(main_res["table"].shape[0]),
             "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(main_res["t_set"], 2)},
             "kernels": {"wrsn_step_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": per_unit * units, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_unit * units, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
                          "whole_step_achieved_GBps": (phys_b + obs_b) * value / 1e9, "whole_step_frac": (phys_b + obs_b) * value / 1e9 / peak},
         }
         if blocking is not None:

@@ -94,7 +94,10 @@ enum wrsn_peek_what {
                                                     n_edges,n_cover                                 */
     WRSN_PEEK_NODE_DEGREE = 7,   /* int32  [B,N]   len(Node.neighbors)                            */
     WRSN_PEEK_NODE_NCOVER = 8,   /* int32  [B,N]   len(Node.listTargets)                          */
-    WRSN_PEEK_NODE_DIRECT = 9    /* int32  [B,N]   node in BaseStation.direct_nodes               */
+    WRSN_PEEK_NODE_DIRECT = 9,   /* int32  [B,N]   node in BaseStation.direct_nodes               */
+    WRSN_PEEK_TARGETS_ACTIVE = 11 /* int32 [B,T]   Network.targets_active (Network.py:9,45-55): target covered by a node the last
+                                                    setLevels reached; 0 beyond an environment's own target count.  (10 is
+                                                    taken by the per-phase cycle counters of diagnostic builds.)       */
 };
 
 /* Create a handle for B environments on cfg->device.  Fails with WRSN_ERR_NO_DEVICE when no HIP
@@ -167,8 +170,13 @@ int wrsn_peek(wrsn_t *h, int32_t what, void *dst);
 /* Wait for the handle's stream. */
 int wrsn_sync(wrsn_t *h);
 
-/* Cumulative device counters since create: [0] simulated node ticks, [1] exact-walk ticks,
- * [2] events dispatched, [3] env-steps executed.  HOST pointer to 4 x int64.  Synchronises. */
+/* Device counters, summed over the environments.  HOST pointer to 8 x int64.  Synchronises.
+ *   [0] simulated seconds, [1] packet-exact seconds, [2] charger events of the episodes in progress (they restart at
+ *       every reset: the warm-up is part of them);
+ *   [3] completed WRSN.step calls since create;
+ *   [4] simulated seconds executed inside WRSN.step calls since create (warm-up excluded, never reset);
+ *   [5] completed WRSN.step calls since create that returned at the instant they were called (the bookkeeping returns
+ *       at t = warm_up_time, SURVEY.md A.4, and same-instant completions);  [6], [7] reserved (0). */
 int wrsn_counters(wrsn_t *h, int64_t *dst);
 
 /* Seeded synthetic network generator (host code): fills HOST arrays

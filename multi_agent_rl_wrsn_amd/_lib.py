@@ -17,6 +17,7 @@ ERR_NAMES = {0: "WRSN_OK", -1: "WRSN_ERR_ARG", -2: "WRSN_ERR_HIP", -3: "WRSN_ERR
 
 PEEK_NODE_ENERGY, PEEK_NODE_CS, PEEK_NODE_RR, PEEK_NODE_STATUS, PEEK_NODE_LEVEL = 0, 1, 2, 3, 4
 PEEK_MC, PEEK_ENV, PEEK_NODE_DEGREE, PEEK_NODE_NCOVER, PEEK_NODE_DIRECT = 5, 6, 7, 8, 9
+PEEK_TARGETS_ACTIVE = 11
 MC_FIELDS = ("loc_x", "loc_y", "energy", "status", "type_charging", "cur_x", "cur_y", "cur_t", "n_conn",
              "excl", "prev_minfit", "act0", "act1", "act2", "_r0", "_r1")
 ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max", "charging_time_max",
@@ -211,6 +212,8 @@ class RawHandle:
             a = np.empty((B, N), dtype=np.float64)
         elif what in (PEEK_NODE_STATUS, PEEK_NODE_LEVEL, PEEK_NODE_DEGREE, PEEK_NODE_NCOVER, PEEK_NODE_DIRECT):
             a = np.empty((B, N), dtype=np.int32)
+        elif what == PEEK_TARGETS_ACTIVE:
+            a = np.empty((B, self.cfg.n_target), dtype=np.int32)
         elif what == PEEK_MC:
             a = np.empty((B, M, 16), dtype=np.float64)
         elif what == PEEK_ENV:
@@ -222,6 +225,7 @@ class RawHandle:
 
     def counters(self):
         import numpy as np
-        a = np.zeros(4, dtype=np.int64)
+        a = np.zeros(8, dtype=np.int64)
         check(self.lib, self.lib.wrsn_counters(self._h, a.ctypes.data))
-        return {"ticks": int(a[0]), "exact_ticks": int(a[1]), "events": int(a[2]), "env_steps": int(a[3])}
+        return {"ticks": int(a[0]), "exact_ticks": int(a[1]), "events": int(a[2]), "env_steps": int(a[3]),
+                "sim_seconds_total": int(a[4]), "zero_time_steps": int(a[5])}

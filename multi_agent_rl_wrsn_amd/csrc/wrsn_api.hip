@@ -424,6 +424,26 @@ int wrsn_peek(wrsn_t* h, int32_t what, void* dst) {
             q[12] = (double)dy[e].n_events; q[13] = dy[e].last_minfit; q[14] = ec[e].n_edges; q[15] = ec[e].n_cover;
         }
         return 0; }
+    case WRSN_PEEK_TARGETS_ACTIVE: {
+        // Network.setLevels marks the targets of every node it reaches (Network.py:45-55); the level words keep what the
+        // last setLevels found (a node that died since keeps its level until the next one, exactly like node.level)
+        const size_t TP = d.TP, T = d.T;
+        std::vector<int32_t> ls(B * NP), off(B * (TP + 1)), idx(B * (size_t)d.CCAP);
+        std::vector<WrsnEnvConst> ec(B);
+        HIPCHK(hipMemcpy(ls.data(), d.live.ls, ls.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(off.data(), d.tc_off, off.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(idx.data(), d.tc_idx, idx.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ec.data(), d.ec, B * sizeof(WrsnEnvConst), hipMemcpyDeviceToHost));
+        int32_t* o = (int32_t*)dst;
+        for (size_t e = 0; e < B; ++e)
+            for (size_t t = 0; t < T; ++t) {
+                int32_t act = 0;
+                if ((int)t < ec[e].n_target)
+                    for (int32_t p = off[e * (TP + 1) + t]; p < off[e * (TP + 1) + t + 1]; ++p)
+                        if ((ls[e * NP + idx[e * (size_t)d.CCAP + p]] >> 1) >= 2) act = 1;     // level >= 1
+                o[e * T + t] = act;
+            }
+        return 0; }
     case 10: {   // diagnostic builds (-DWRSN_PROFILE): int64 [B,25] per-phase cycle totals (+ whole kernel); zeros otherwise
         HIPCHK(hipMemcpy(dst, d.counters, B * 25 * sizeof(int64_t), hipMemcpyDeviceToHost));
         return 0; }
@@ -439,8 +459,11 @@ int wrsn_counters(wrsn_t* h, int64_t* dst) {
     std::vector<WrsnEnvDyn> dy(B);
     HIPCHK(hipMemcpy(dy.data(), h->dev.live.dyn, B * sizeof(WrsnEnvDyn), hipMemcpyDeviceToHost));
     // n_ticks / n_exact / n_events restart at every reset (they live in the snapshot); n_steps is cumulative
-    dst[0] = dst[1] = dst[2] = dst[3] = 0;
-    for (size_t e = 0; e < B; ++e) { dst[0] += dy[e].n_ticks; dst[1] += dy[e].n_exact; dst[2] += dy[e].n_events; dst[3] += dy[e].n_steps; }
+    for (int k = 0; k < 8; ++k) dst[k] = 0;
+    for (size_t e = 0; e < B; ++e) {
+        dst[0] += dy[e].n_ticks; dst[1] += dy[e].n_exact; dst[2] += dy[e].n_events; dst[3] += dy[e].n_steps;
+        dst[4] += dy[e].tot_ticks; dst[5] += dy[e].tot_zero_steps;
+    }
     return WRSN_OK;
 }
 

@@ -1954,6 +1954,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     const WrsnEnvConst* ec = s.EC();
     s.load(do_reset ? dp->snap : dp->live);
     if (do_reset) s.dirty = 7;                             // the snapshot goes to the live arrays in full
+    const int64_t ticks0 = s.n_ticks;
     int terminal = 0, susp = 0;
     if (do_reset) {
         const double* rs = dp->snap.ring + (size_t)env * WRSN_RING * s.NP; double* rl = dp->live.ring + (size_t)env * WRSN_RING * s.NP;
@@ -1979,6 +1980,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
         }
         if (lane == 0 && !resume) {
             int st0 = 0;
+            dp->live.dyn[env].step_t0 = s.now;
             if (aid >= 0 && aid < s.M) {
                 double act[3];
                 for (int k = 0; k < 3; ++k) { double v = action[(size_t)env * 3 + k]; act[k] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }   // np.clip (WRSN.py:299)
@@ -2045,6 +2047,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
                 if (agent >= 0) dy->roll[agent] += reward;
                 if (terminal) { dy->roll[WRSN_MAX_MC] += 1.0; dy->roll[WRSN_MAX_MC + 1] += s.now; }
                 dy->roll[WRSN_MAX_MC + 2] += 1.0;
+                if (s.now == dy->step_t0) dy->tot_zero_steps += 1;
             }
             if (out.agent_id) out.agent_id[env] = agent;
             if (out.reward) out.reward[env] = reward;
@@ -2056,6 +2059,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     }
     s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp);
     if (lane == 0 && reset_call) dp->live.dyn[env].listed_for = 0;   // a reset launch takes the environment off the in-flight list
+    if (lane == 0 && !do_reset) dp->live.dyn[env].tot_ticks += s.n_ticks - ticks0;
 #ifdef WRSN_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
 #if WRSN_PROFILE >= 3

@@ -52,6 +52,10 @@ struct WrsnEnvDyn {
     double node_time; int64_t node_seq;      // the block of Node.operate timeouts
     double last_minfit, opmax;
     int64_t n_ticks, n_exact, n_events, n_steps;
+    // cumulative since create, never reset: simulated seconds executed by WRSN.step calls (warm-up excluded), completed
+    // WRSN.step calls that returned at the instant they started (the bookkeeping returns at t = warm_up_time)
+    int64_t tot_ticks, tot_zero_steps;
+    double step_t0;                          // env.now when the WRSN.step in progress (or last completed) was called
     int32_t net_phase, net_active, node_phase, alive;
     int32_t levels_dirty, cache_dirty, irreg, ring_len;
     int32_t ring_head, safe_ticks, frozen, terminal_pending;

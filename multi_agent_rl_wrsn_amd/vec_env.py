@@ -165,6 +165,10 @@ class VecWRSN:
         p = self._h.peek
         return {"degree": p(_lib.PEEK_NODE_DEGREE), "n_cover": p(_lib.PEEK_NODE_NCOVER), "direct": p(_lib.PEEK_NODE_DIRECT)}
 
+    def targets_active(self):
+        """Network.targets_active (Network.py:9, 45-55) per environment: int32 [B, T]."""
+        return self._h.peek(_lib.PEEK_TARGETS_ACTIVE)
+
     def mcs(self):
         a = self._h.peek(_lib.PEEK_MC)
         return {k: a[:, :, i].copy() for i, k in enumerate(_lib.MC_FIELDS) if not k.startswith("_")}

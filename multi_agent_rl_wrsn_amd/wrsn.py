@@ -46,6 +46,12 @@ class _NodeView:
         self.energy = self.capacity; self.energyCS = 0.0; self.energyRR = 0.0; self.status = 1; self.level = None
 
 
+class _TargetView:                                           # Target.py:1-4
+    def __init__(self, i, xy):
+        self.id = i
+        self.location = [float(xy[0]), float(xy[1])]
+
+
 class _BaseStationView:
     def __init__(self, xy):
         self.location = np.array(xy, dtype=np.float64)
@@ -60,6 +66,7 @@ class _NetView:
         self.env = owner.env
         self.baseStation = _BaseStationView(sc.bs_xy)
         self.listNodes = [_NodeView(i, sc.node_xy[i], sc.node_spec) for i in range(sc.n_node)]
+        self.listTargets = [_TargetView(i, sc.target_xy[i]) for i in range(sc.n_target)]
         self.max_time = sc.max_time
         self.frame = sc.frame()
         self.nodes_density = sc.n_node / ((self.frame[1] - self.frame[0]) * (self.frame[3] - self.frame[2]))
@@ -74,6 +81,13 @@ class _NetView:
     @property
     def alive(self):
         return int(self._o.vec.env_info()["alive"][0])
+
+    @property
+    def targets_active(self):                                # Network.py:9; read by runner/checkRL.py:25-27
+        return [int(v) for v in self._o.vec.targets_active()[0, :self._o.scenario.n_target]]
+
+    def check_targets(self):                                 # Network.py:84-85
+        return min(self.targets_active)
 
     def check_nodes(self):                                   # Network.py:87-92
         return int((self._o.vec.nodes()["status"][0] == 0).sum())

@@ -45,6 +45,72 @@ def six_node():
     return s
 
 
+def redundant_net(capacity=1000.0, max_time=None):
+    """Hand-made network with redundant coverage, so that nodes die WITHOUT ending the episode (Node.py:92-132,
+    Network.py:69-81).  A hub of 12 mutually adjacent nodes next to the base station (every hub node has > 8
+    neighbours, the hub targets have > 8 covering nodes) relays the packets of source sites further west; a hub node
+    that carries a site spends 2.5 x what the sources spend, runs dry first and the site falls back on the next hub
+    node at once (Node.py:93-94 tests the live status).  Sites come in mirror-image pairs (their carriers run dry in the
+    same second) and every site is two nodes that cover the same targets.  To the east a ladder of two cross-linked
+    chains (a rung target is covered by both chains; when a chain's head dies the other takes over through the cross
+    links after the next setLevels).  Low node capacity: all of this happens within a few decisions."""
+    s = dict(scen("hanoi1000n50"))
+    spec = dict(s["node_phy_spe"]); spec["capacity"] = capacity
+    s["node_phy_spe"] = spec
+    if max_time is not None:
+        s["max_time"] = max_time
+    rng = np.random.RandomState(12345)
+    nodes, targets = [], []
+    hub_c = (440.0, 500.0)
+    for k in range(6):                                        # hub: 6 mirror pairs inside a 24 m disc
+        r = 6.0 + 18.0 * rng.rand(); a = np.pi * (0.08 + 0.84 * rng.rand())
+        dx, dy = float(np.round(r * np.cos(a), 1)), float(np.round(abs(r * np.sin(a)) + 1.0, 1))
+        nodes.append([hub_c[0] + dx, hub_c[1] + dy]); nodes.append([hub_c[0] + dx, hub_c[1] - dy])
+    for t in range(3):
+        targets.append([hub_c[0] + 3.0 * t - 3.0, hub_c[1]])
+    for (ox, oy, nt) in ((-58.0, 30.0, 14), (-30.0, 62.0, 10)):   # source sites (mirrored in y), two nodes each
+        for sign in (+1.0, -1.0):
+            cx, cy = hub_c[0] + ox, hub_c[1] + sign * oy
+            nodes.append([cx, cy]); nodes.append([cx - 9.0, cy + sign * 12.0])
+            for t in range(nt):
+                targets.append([cx - 5.0 - 1.5 * t, cy + sign * (4.0 + 0.5 * t)])
+    for k in range(5):                                        # ladder to the east: chains A (y = 521) and B (y = 481)
+        x = 561.0 + 70.0 * k
+        nodes.append([x, 521.0]); nodes.append([x, 481.0])
+        targets.append([x - 5.0, 501.0])
+    s["nodes"] = nodes; s["targets"] = targets
+    return s
+
+
+def synth_tree(seed, n_node, n_target):
+    """Seeded chain-like relay trees around the base station (the shape of the shipped scenarios: mean degree ~2.2),
+    every target inside the sensing range of a node: a 300-node network for the multi-register-slot kernels."""
+    s = dict(scen("hanoi1000n50"))
+    rng = np.random.RandomState(seed)
+    com, sen = float(s["node_phy_spe"]["com_range"]), float(s["node_phy_spe"]["sen_range"])
+    side = 1000.0 * max(1.0, np.sqrt(n_node / 200.0)); bs = np.array([side / 2, side / 2])
+    pts = []; tips = []
+    while len(pts) < n_node:
+        if len(pts) < 3:
+            a = rng.uniform(0, 2 * np.pi); r = rng.uniform(0.35 * com, 0.95 * com); p = bs + r * np.array([np.cos(a), np.sin(a)]); par = -1
+        else:
+            par = tips[rng.randint(len(tips))] if (tips and rng.rand() < 0.93) else rng.randint(len(pts))
+            o = pts[par] - bs; a = np.arctan2(o[1], o[0]) + 0.75 * rng.randn(); r = rng.uniform(0.62 * com, 0.995 * com)
+            p = pts[par] + r * np.array([np.cos(a), np.sin(a)])
+        if p.min() < 0 or p.max() > side or any(np.hypot(*(q - p)) < 0.56 * com for q in pts):
+            continue
+        if par in tips: tips.remove(par)
+        pts.append(p); tips.append(len(pts) - 1); tips[:] = tips[-24:]
+    tg = []
+    for _ in range(n_target):
+        o = pts[rng.randint(n_node)]; a = rng.uniform(0, 2 * np.pi); r = 0.93 * sen * np.sqrt(rng.rand())
+        tg.append(o + r * np.array([np.cos(a), np.sin(a)]))
+    s["base_station"] = [float(bs[0]), float(bs[1])]
+    s["nodes"] = [[float(np.round(p[0], 3)), float(np.round(p[1], 3))] for p in pts]
+    s["targets"] = [[float(np.round(p[0], 3)), float(np.round(p[1], 3))] for p in tg]
+    return s
+
+
 def frame_of(s):
     xs = [p[0] for p in s["nodes"]] + [s["base_station"][0]]
     ys = [p[1] for p in s["nodes"]] + [s["base_station"][1]]
@@ -77,12 +143,37 @@ def snapshot(env):
     )
 
 
-def run_case(name, s, mc, M, actions, max_steps, WRSN, map_size=100, warm_up=100):
+class MinimizeRecorder:
+    """Wraps the `minimize` name the reference's WRSN module imported from SciPy (WRSN.py:8, :249) and keeps what the
+    reference itself passed and got back: start point, bounds, the optimiser's result x, and the value of the
+    reference's own objective_function at the start point and at x (the reference only uses x; `res.fun` is kept too --
+    after a failed line search on this discontinuous objective it is not always the value at x)."""
+
+    def __init__(self, module):
+        self.module = module; self.orig = module.minimize; self.calls = []
+        module.minimize = self
+
+    def __call__(self, fun, x0, **kw):
+        res = self.orig(fun, x0, **kw)
+        self.calls.append(dict(x0=np.array(x0, dtype=np.float64), bounds=np.array(kw.get("bounds"), dtype=np.float64),
+                               x=np.array(res.x, dtype=np.float64), fun=float(fun(res.x)), fun_x0=float(fun(x0)), fun_reported=float(res.fun)))
+        return res
+
+    def close(self):
+        self.module.minimize = self.orig
+
+
+def run_case(name, s, mc, M, actions, max_steps, WRSN, map_size=100, warm_up=100, density_map=False):
     tf = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False)
     yaml.safe_dump(s, tf); tf.close()
     tm = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False)
     yaml.safe_dump(mc, tm); tm.close()
-    env = WRSN(tf.name, tm.name, M, map_size=map_size, warm_up_time=warm_up, density_map=False)
+    env = WRSN(tf.name, tm.name, M, map_size=map_size, warm_up_time=warm_up, density_map=density_map)
+    recorder = None
+    if density_map:
+        import rl_env.WRSN as wrsn_module
+        recorder = MinimizeRecorder(wrsn_module)
+    dm = {k: [] for k in ("in_map", "dm_x0", "dm_bounds", "dm_x", "dm_fun", "dm_fun_x0", "dm_fun_reported")}
     req = env.reset()
     rec = {k: [] for k in ("in_agent", "in_action", "agent_id", "now", "reward", "terminal", "is_none",
                            "obs_sample")}
@@ -94,8 +185,20 @@ def run_case(name, s, mc, M, actions, max_steps, WRSN, map_size=100, warm_up=100
     for i in range(max_steps):
         aid = req["agent_id"]
         a = np.asarray(actions(i, req), dtype=np.float64)
+        if density_map:
+            # the policy's G x G map, made exactly representable in float32 (the fixture stores it as such); in_action is
+            # the 3-vector the reference itself derived from it (WRSN.py:293-299), so that the physics of the fixture
+            # can be replayed through the 3-vector path
+            a = a.astype(np.float32).astype(np.float64)
+            n0 = len(recorder.calls)
         req = env.step(aid, a)
         rec["in_agent"].append(-1 if aid is None else aid)
+        if density_map:
+            c = recorder.calls[n0]; assert len(recorder.calls) == n0 + 1
+            dm["in_map"].append(a.astype(np.float32))
+            for k in ("x0", "bounds", "x", "fun", "fun_x0", "fun_reported"):
+                dm["dm_" + k].append(c[k])
+            a = np.array(env.agents_action[aid], dtype=np.float64)
         rec["in_action"].append(a)
         if req is None:      # WRSN.step fell off the end (WRSN.py:321-330 has no else)
             rec["is_none"].append(1); rec["agent_id"].append(-1); rec["now"].append(env.env.now)
@@ -118,6 +221,8 @@ def run_case(name, s, mc, M, actions, max_steps, WRSN, map_size=100, warm_up=100
         if req["terminal"]:
             break
     os.unlink(tf.name); os.unlink(tm.name)
+    if recorder is not None:
+        recorder.close()
     out = dict(
         node_xy=np.array(s["nodes"], dtype=np.float64), target_xy=np.array(s["targets"], dtype=np.float64),
         bs_xy=np.array(s["base_station"], dtype=np.float64),
@@ -135,14 +240,18 @@ def run_case(name, s, mc, M, actions, max_steps, WRSN, map_size=100, warm_up=100
         obs_full=np.array(obs_full, dtype=np.float64).reshape(-1, 4, map_size, map_size),
         reset_agent=np.int32(reset_agent), reset_obs=reset_obs,
     )
+    if density_map:
+        out["in_map"] = np.array(dm["in_map"], dtype=np.float32)
+        for k in ("dm_x0", "dm_bounds", "dm_x", "dm_fun", "dm_fun_x0", "dm_fun_reported"):
+            out[k] = np.array(dm[k], dtype=np.float64)
     for k, v in reset_snap.items():
         out["reset_" + k] = v
     for k in snaps[0]:
         out[k] = np.array([sn[k] for sn in snaps])
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
-    print("%-34s decisions=%d end_now=%.3f terminal=%d dead_nodes=%d" % (
-        name, len(rec["now"]), rec["now"][-1], rec["terminal"][-1], int((snaps[-1]["node_status"] == 0).sum())), flush=True)
+    print("%-34s decisions=%d end_now=%.3f terminal=%d dead_nodes=%s" % (
+        name, len(rec["now"]), rec["now"][-1], rec["terminal"][-1], [int((sn["node_status"] == 0).sum()) for sn in snaps]), flush=True)
 
 
 def rnd(seed):
@@ -178,6 +287,54 @@ def main():
         if sel and not any(x in c[0] for x in sel):
             continue
         run_case(c[0], c[1], c[2], c[3], c[4], c[5], WRSN)
+    # ---- round 2: semantics the cases above never reach
+    red = redundant_net()
+    def short(seed, tmax):
+        rng = np.random.RandomState(seed)
+        return lambda i, req: np.array([rng.rand(), rng.rand(), tmax * rng.rand()])
+    extra = [
+        # nodes die without ending the episode, several in one second, re-levelling, > 8 neighbours / covering nodes
+        ("redundant_m2_deaths", red, mc, 2, short(21, 0.6), 60, {}),
+        ("redundant_m3_deaths", red, mc, 3, short(22, 1.0), 60, {}),
+        # Network.operate stops at max_time (Network.py:78-79): levels and `alive` freeze, steps continue, nodes die
+        ("redundant_m2_maxtime130", redundant_net(max_time=130), mc, 2, short(23, 0.8), 24, {}),
+        ("hanoi1000n50_m3_maxtime400", dict(scen("hanoi1000n50"), max_time=400), mc, 3, rnd(24), 12, {}),
+        # 64 x 64 observation
+        ("hanoi1000n50_m2_map64", scen("hanoi1000n50"), mc, 2, rnd(25), 12, dict(map_size=64)),
+        ("redundant_m2_map64", red, mc, 2, short(26, 0.5), 16, dict(map_size=64)),
+        # 300 nodes: two register slots per lane are not enough (NPL = 8 kernels), CSR neighbour lists
+        ("synth300_m3_s27", synth_tree(27, 300, 150), mc, 3, short(27, 0.05), 7, {}),
+    ]
+    for name, sc_, mc_, M_, pol, n_, kw in extra:
+        if sel and not any(x in name for x in sel):
+            continue
+        run_case(name, sc_, mc_, M_, pol, n_, WRSN, **kw)
+    # ---- density_map=True (WRSN.py:229-297, what runner/IPPO.py and runner/checkRL.py use): the policy emits a G x G map
+    def map_policy(seed, G):
+        rng = np.random.RandomState(seed)
+        def pol(i, req):
+            kind = i % 5
+            if kind == 0:                                      # logits
+                return rng.randn(G, G) * (1.0 + (i // 5) % 3)
+            if kind == 1:                                      # the heuristic of controller/random/RandomController.py:15
+                st = req["state"]
+                return st[0] + st[1] - 10 * st[2] + st[3]
+            if kind == 2:                                      # a peaked map of non-negative weights (goes through exp)
+                m = rng.rand(G, G) ** 8
+                return m / m.sum()
+            if kind == 3:                                      # flat: ties at the percentile and at the arg-max
+                return np.full((G, G), 0.5)
+            m = np.zeros((G, G)); m[rng.randint(G), rng.randint(G)] = 1.0     # one-hot: a valid probability map
+            return m
+        return pol
+    dens = [
+        ("hanoi1000n50_m3_density", scen("hanoi1000n50"), mc, 3, map_policy(31, 100), 20, dict(density_map=True)),
+        ("redundant_m2_density_map64", red, mc, 2, map_policy(32, 64), 20, dict(density_map=True, map_size=64)),
+    ]
+    for name, sc_, mc_, M_, pol, n_, kw in dens:
+        if sel and not any(x in name for x in sel):
+            continue
+        run_case(name, sc_, mc_, M_, pol, n_, WRSN, **kw)
     # network-only plumbing (runner/test_network.py): state after `run(until=t)` with no charger activity
     if not sel or any("warmup" in x for x in sel):
         for t in (1, 10, 37):

@@ -50,6 +50,9 @@ class EmuVec:
         return {"energy": self.h.peek(_lib.PEEK_NODE_ENERGY), "cs": self.h.peek(_lib.PEEK_NODE_CS), "rr": self.h.peek(_lib.PEEK_NODE_RR),
                 "status": self.h.peek(_lib.PEEK_NODE_STATUS), "level": self.h.peek(_lib.PEEK_NODE_LEVEL)}
 
+    def targets_active(self):
+        return self.h.peek(_lib.PEEK_TARGETS_ACTIVE)
+
     def mcs(self):
         a = self.h.peek(_lib.PEEK_MC)
         return {k: a[:, :, i].copy() for i, k in enumerate(_lib.MC_FIELDS)}

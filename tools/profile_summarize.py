@@ -2,6 +2,11 @@
 profiles/<tag>_traffic.json (run on the GPU box; the outputs come back through gpurun_out/)."""
 import collections, csv, glob, json, os, shutil, sys
 out, tag = sys.argv[1], sys.argv[2]
+# configuration of the profiled bench command (bench.py attaches `traffic` only to a run of the same configuration)
+cfg = {"envs_per_gpu": 4096, "nodes": 200, "targets": 200, "chargers": 3, "map_size": 100, "step_budget": 1500}
+for a in sys.argv[3:]:
+    k, v = a.split("="); cfg[k] = int(v)
+min_grid = 64 * cfg["envs_per_gpu"]
 dst = os.path.join(os.path.dirname(out), "profiles_" + tag)
 os.makedirs(dst, exist_ok=True)
 st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -13,13 +18,13 @@ def pmc(sub, name):
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != name: continue
         k = "wrsn_step_kernel" if "wrsn_step_kernel" in r["Kernel_Name"] else ("wrsn_obs_kernel" if "wrsn_obs_kernel" in r["Kernel_Name"] else None)
-        if k is None or int(r["Grid_Size"]) < 64 * 1024: continue          # the bench launches only (4096 environments)
+        if k is None or int(r["Grid_Size"]) < min_grid: continue          # the bench launches only (4096 environments)
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     return agg
 fe, wr = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md HBM section) of "
                "`python3 bench.py --steps 40 --warmup 10 --cpu-seconds 0 --kernel-steps 5 --no-blocking-run` (default step budget); counters are KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
-               "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B: doubled, an upper bound for narrower accesses)", "kernels": {}}
+               "(gfx950 FETCH_SIZE tallies 128-B requests at 64 B: doubled, an upper bound for narrower accesses)", "config": cfg, "kernels": {}}
 for k in ("wrsn_step_kernel", "wrsn_obs_kernel"):
     if fe[k][1] and wr[k][1]:
         f = fe[k][0] / fe[k][1]; w = wr[k][0] / wr[k][1]
