@@ -60,6 +60,8 @@ struct wrsn_handle {
     int slots;                 // wave slots of the device for the step kernel (CUs x 8): launch-order dependent budgets
     long long epoch;           // launch counter of budgeted wrsn_step calls (epoch % 3 selects the in-flight list)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
+    int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
+    int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     std::vector<void*> allocs;
     WrsnDev* d_dev;            // device copy of `dev`: the environment kernels read it through the constant cache
 };
@@ -98,16 +100,24 @@ int alloc_node_arrays(wrsn_handle* h, WrsnNodeArrays* a) {
 
 int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agent_id, const double* action,
                int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out) {
-    const int lds = h->lds_env;
+    const int lds = h->lds_env + h->lds_pad;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
     dim3 grid(budget > 0 ? 2 * nenv : nenv), block(64);
     long long epoch = 0;
     if (budget > 0) epoch = ++h->epoch;                        // the kernel itself empties the list the launch after it fills
+    // A budgeted step is two launches: the lean variant of the step kernel over all environments (no code for the level BFS,
+    // the routing rebuild and the packet-exact second: no scratch memory), then the full variant over the few environments
+    // the lean one stopped in front of such a service (hand-off list; the other blocks leave at once).
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
-    else hipLaunchKernelGGL(wrsn_step_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                            auto_reset, budget, epoch, h->slots, mask, out)
+    else if (budget > 0 && h->split) {                                                                                 \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                           auto_reset, budget, epoch, h->slots, mask, out, 1);                                         \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv), block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                           auto_reset, budget, epoch, h->slots, mask, out, 2);                                         \
+    } else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                            auto_reset, budget, epoch, h->slots, mask, out, 0)
     switch (h->npl) {
     case 1: WRSN_LAUNCH(1); break;
     case 2: WRSN_LAUNCH(2); break;
@@ -169,6 +179,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
     h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1;
+    { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
+    { const char* e = std::getenv("WRSN_LDS_PAD"); h->lds_pad = e ? std::atoi(e) : 0; if (h->lds_pad < 0 || h->lds_pad > 100000) h->lds_pad = 0; }
     { hipDeviceProp_t pr; h->slots = (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount * 8 : 2048; }
     h->npl = npl_for(cfg->n_node);
     if (h->npl < 0) { delete h; return fail(WRSN_ERR_ARG, "n_node too large"); }
@@ -213,6 +225,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.prio_list, 3 * B))) break;
         if ((rc = dalloc(h, &d.prio_n, 3))) break;
         if ((rc = dalloc(h, &d.render_agent, B))) break;
+        if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
+        if ((rc = dalloc(h, &d.heavy_n, 2))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
     } while (0);
     if (rc) { wrsn_destroy(h); return rc; }
@@ -317,6 +331,7 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     if ((work_units > 0) != (h->step_budget > 0)) {            // (re)entering budgeted mode: no environment is listed yet
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemset(h->dev.prio_n, 0, 3 * sizeof(int32_t)));
+        HIPCHK(hipMemset(h->dev.heavy_n, 0, 2 * sizeof(int32_t)));
         h->epoch += 4;                                         // stamps left by earlier budgeted launches name no future launch
     }
     h->step_budget = work_units;

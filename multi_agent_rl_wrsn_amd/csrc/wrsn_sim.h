@@ -23,7 +23,26 @@
 #define WRSN_CHG_MAX 8                    // nodes under charge handled by the time-parallel steady batch
 // Diagnostic build only (-DWRSN_PROFILE, tools/build_profile.sh): per-phase cycle totals per environment.  Stamps go
 // to a buffer of their own (WrsnDev.counters) and no output is computed from them; the product build has none.
-#if defined(WRSN_PROFILE) && WRSN_PROFILE >= 2
+#if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
+// level 4: breakdown of the scalar event processor and of the service loop (slots listed in tools/diag_scalar.py)
+#define WRSN_P4_MARK(var) const long long var = clock64();
+#define WRSN_P4_SPAN(slot, a, b) prof_[slot] += (b) - (a);
+#define WRSN_P4_CNT(slot, v) prof_[slot] += (v);
+#else
+#define WRSN_P4_MARK(var)
+#define WRSN_P4_SPAN(slot, a, b)
+#define WRSN_P4_CNT(slot, v)
+#endif
+#if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
+#define WRSN_PROF_DECL long long prof_[24]; long long prof_t_;
+#define WRSN_PROF_ZERO for (int q_ = 0; q_ < 24; ++q_) prof_[q_] = 0;
+#define WRSN_PROF_MARK(var)
+#define WRSN_PROF_SPAN(slot, a, b)
+#define WRSN_PROF_T0
+#define WRSN_PROF_ADD(slot)
+#define WRSN_PROF_CNT(slot, v)
+#define WRSN_PROF_EV(slot, v)
+#elif defined(WRSN_PROFILE) && WRSN_PROFILE >= 2
 // level 2: event histogram instead of phase timers (slot = process hop fired; 19.. = service kinds)
 #define WRSN_PROF_DECL long long prof_[24]; long long prof_t_;
 #define WRSN_PROF_ZERO for (int q_ = 0; q_ < 24; ++q_) prof_[q_] = 0;
@@ -205,7 +224,12 @@ WDEV void wrsn_lds_gather8_b64(const double* base, const int (&idx)[8], double (
 }
 #endif
 
-template <int NPL>
+// HEAVY = false builds the lean variant of the simulator for the common path of a step: it holds no code for the three
+// rare, register-hungry services -- the level BFS after a death (set_levels), the routing-cache rebuild (rebuild_cache)
+// and the packet-exact second (exact_walk).  When a grid item needs one of them the lean variant stops in front of that
+// item exactly like an environment that ran out of its launch budget (`need_heavy`), and the full variant goes on with
+// it in a second, small launch (wrsn_step_kernel<NPL, true> over the hand-off list).
+template <int NPL, bool HEAVY = true>
 struct Sim {
     // identity / geometry.  Pointers are not kept as members: they are derived on demand from the device descriptor
     // (scalar loads from the constant cache) and from the LDS base, which keeps the hot per-second loop small in
@@ -229,6 +253,7 @@ struct Sim {
     double teps;                                             // energy margin of the "may a node run dry" tests
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
+    int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has
     double last_minfit;
     WRSN_PROF_DECL
 
@@ -298,7 +323,7 @@ struct Sim {
         cap = wu(EC()->capacity); thr = wu(EC()->threshold); max_time = wu(EC()->max_time);
         inv_a_b2 = wu((EC()->beta * EC()->beta) / EC()->alpha);
         teps = wu(1e-9 * cap);
-        err = 0; deaths_flag = 0;
+        err = 0; deaths_flag = 0; need_heavy = 0;
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
 
@@ -449,6 +474,7 @@ struct Sim {
 
     // -------------------------------------------------------------- Network.setLevels + check_targets (Network.py:37-66, 84-85)
     WDEV void set_levels() { WRSN_PROF_T0
+        if constexpr (!HEAVY) { need_heavy = 1; return; } else {
         int oldlv[NPL];
         if (NPL <= 4) {
             // Up to 256 nodes: node sets are NPL 64-bit masks (one ballot per register slot) and the neighbourhood of a
@@ -536,12 +562,14 @@ struct Sim {
         alive = wv_any(bad) ? 0 : 1;
         levels_dirty = 0; work += 100; dirty |= 2;
         WRSN_PROF_ADD(6)
+        }
     }
 
     // -------------------------------------------------------------- routing cache: receivers + per-tick drains
     // rcv_i = Node.find_receiver (Node.py:92-100) / base station (Node.py:108-111); c1/c2 = packets relayed per tick that
     // arrive before / after the node's own half-charge (sources with lower / higher id; Node.py:57-62 runs in id order).
     WDEV void rebuild_cache() { WRSN_PROF_T0
+        if constexpr (!HEAVY) { need_heavy = 1; return; } else {
         int32_t* c1 = (int32_t*)SU(); int32_t* c2 = c1 + NP;
         double es[NPL]; int rc[NPL], wsl[NPL];
         const double er = EC()->e_recv;
@@ -592,6 +620,7 @@ struct Sim {
         opmax = wv_max(opm);
         cache_dirty = 0; irreg = WRSN_RING; safe_ticks = 0; work += 80; dirty |= 1;
         WRSN_PROF_ADD(5)
+        }
     }
 
     // -------------------------------------------------------------- exact k+0.5 instant (a node may run dry this second)
@@ -770,6 +799,7 @@ struct Sim {
     }
 
     WDEV void exact_walk(const double (&rrh)[NPL], bool any_rr) { WRSN_PROF_T0
+        if constexpr (!HEAVY) { need_heavy = 1; (void)rrh; (void)any_rr; return; } else {
         double es[NPL], gain[NPL], e_start[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) { e_start[j] = E[j]; gain[j] = 0.0; }
@@ -843,11 +873,12 @@ struct Sim {
         (void)any_rr;
         __syncthreads();
         WRSN_PROF_ADD(4)
+        }
     }
 
     // -------------------------------------------------------------- k+0.5: Node.operate first half for all nodes (Node.py:57-62)
     WDEV void node_half(const double (&rrh)[NPL], const bool any_rr) {
-        if (cache_dirty) rebuild_cache();
+        if (cache_dirty) { rebuild_cache(); if (!HEAVY) return; }
         bool fast = true;
         if (safe_ticks > 0) { safe_ticks--; }
         else {
@@ -868,6 +899,7 @@ struct Sim {
                 }
             }
             fast = !wv_any(trig != 0);
+            if (!HEAVY && !fast) { need_heavy = 1; return; }  // nothing was touched: the full variant takes this item again
             if (!fast) {                                     // who: the exact second starts from the critical source when it is one node
                 uns_cnt = 0; uns_node = -1;
 #pragma unroll
@@ -1296,10 +1328,12 @@ struct Sim {
                 // ---- one item (every O(N) routine has exactly one call site: the kernel has to fit the instruction cache)
                 WRSN_PROF_CNT(15, 1) work += 8;
                 WRSN_PROF_MARK(gi0_)
+                const double now_before = now;
                 now = bt;
                 if (k == 0) {
                     if (net_phase == 0) {                    // Network.py:75-78
                         if (levels_dirty) set_levels();
+                        if (!HEAVY && need_heavy) { now = now_before; break; }
                         if (alive == 0) frozen = 1;          // terminal at the next return; node state is no longer observable
                         net_phase = 1; net_time = now + 9.0 * 1.0 / 10.0; net_seq = seq++;
                     } else {                                 // Network.py:78-80
@@ -1310,7 +1344,11 @@ struct Sim {
                     do_ur = ur_flag; nrep = do_ur ? 1 : 0;
                     ur_time = now + 1.0; ur_seq = seq++;
                 } else {
-                    if (node_phase == 0) { node_half(rrh, any_rr); node_phase = 1; } else { node_full(rrh, any_rr); node_phase = 0; }
+                    if (node_phase == 0) {
+                        node_half(rrh, any_rr);
+                        if (!HEAVY && need_heavy) { now = now_before; break; }
+                        node_phase = 1;
+                    } else { node_full(rrh, any_rr); node_phase = 0; }
                     node_time = now + 1.0 * 0.5; node_seq = seq++;
                 }
                 WRSN_PROF_MARK(gi1_) WRSN_PROF_SPAN(8, gi0_, gi1_)
@@ -1667,6 +1705,7 @@ struct Sim {
     WDEV int scalar_loop(EvCache& ev, const int L, const int pend0, const int pend_idx0, int* pend_out, double svc, bool use_limit, double limit,
                          int* arg, double* t_lim_out, int* flags_out) {
         WRSN_PROF_MARK(sr0_)
+        WRSN_P4_MARK(q0_)
         switch (pend0) {                                      // finish the item that asked for the service
         case REQ_PRECHECK: p_init_tail(pend_idx0, svc); ev.valid = 0; break;
         case REQ_CONN: mc_charge_loop(pend_idx0); ev.valid = 0; break;
@@ -1678,10 +1717,11 @@ struct Sim {
             break;
         default: break;
         }
-        
+        WRSN_P4_MARK(q1_) WRSN_P4_SPAN(8, q0_, q1_)
         for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
             WRSN_PROF_MARK(sc0_)
-            if (!ev.valid) {                                 // charger / condition state only changes when one of them fires
+            WRSN_P4_CNT(1, 1) WRSN_P4_MARK(q2_)
+            if (!ev.valid) { WRSN_P4_CNT(3, 1)                                 // charger / condition state only changes when one of them fires
                 int kind_ = -1, idx_ = 0; double bt_ = 0.0; int bp_ = 0; int64_t bs_ = 0; double t2_ = WRSN_INF;
 #define WRSN_CONSIDER(K, I, T_, P_, S_) { const double tt_ = (T_); \
                     if (kind_ < 0 || key_less(tt_, (P_), (S_), bt_, bp_, bs_)) { if (kind_ >= 0 && bt_ < t2_) t2_ = bt_; kind_ = (K); idx_ = (I); bt_ = tt_; bp_ = (P_); bs_ = (S_); } \
@@ -1703,8 +1743,10 @@ struct Sim {
                     for (int q = 0; q < 4; ++q) if (j0 + q <= L && pd[q]) WRSN_CONSIDER(4, j0 + q, tt[q], WRSN_NORMAL, sq[q])
                 }
 #undef WRSN_CONSIDER
+ WRSN_P4_MARK(q3_) WRSN_P4_SPAN(2, q2_, q3_)
                 ev.kind = kind_; ev.idx = idx_; ev.time = bt_; ev.prio = bp_; ev.seq = bs_; ev.t2 = t2_; ev.valid = 1; ev.uf = -1;
             }
+            WRSN_P4_MARK(q4_)
             
             const int kind = ev.kind, idx = ev.idx, bp = ev.prio; const double bt = ev.time; const int64_t bs = ev.seq;
             const bool have_ev = kind >= 0;
@@ -1720,9 +1762,11 @@ struct Sim {
             if (use_limit && limit < t_lim) t_lim = limit;
             if (have_grid && (gt < t_lim || (have_ev && gt == bt)) && ev.uf < 0) {
                 // the reward entry list is only needed by a grid service: (re)build it lazily
+ WRSN_P4_MARK(q5_) WRSN_P4_CNT(5, 1)
                 WRSN_PROF_MARK(uf0_)
                 ev.uf = ur_flags();
                 if (ev.uf & 1) ur_build(); else SURN()[0] = 0;
+                WRSN_P4_MARK(q6_) WRSN_P4_SPAN(4, q5_, q6_)
                 
                 WRSN_PROF_EV(21, 1) WRSN_PROF_EV(23, SURN()[0])
             }
@@ -1731,10 +1775,11 @@ struct Sim {
             const bool tie_ok = have_ev && t_lim == bt && bp == WRSN_NORMAL;
             if (have_grid && (gt < t_lim || (tie_ok && gt == bt && gs < bs))) {
                 const int uf = ev.uf;
-                if (uf & 2) { ff_sync_all(gt); ur_build(); *arg = 1; }   // stale "charging" mover: one item at a time, location kept current
+                if (uf & 2) { WRSN_P4_MARK(q7_) ff_sync_all(gt); ur_build(); *arg = 1; WRSN_P4_MARK(q8_) WRSN_P4_SPAN(9, q7_, q8_) }   // stale "charging" mover: one item at a time, location kept current
                 else if (tie_ok) { *arg = 2; ((int64_t*)SREQD())[3] = bs; }
                 else *arg = 0;
                 *t_lim_out = t_lim; *flags_out = uf & 1;
+                WRSN_P4_MARK(q9_) WRSN_P4_SPAN(10, q4_, q9_)
                 WRSN_PROF_EV(19, 1) WRSN_PROF_EV(20, (uf & 2) ? 1 : 0)
                 *pend_out = REQ_GRID; return REQ_GRID;
             }
@@ -1747,9 +1792,12 @@ struct Sim {
                 *pend_out = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
             }
             now = bt; ev.fired++; ev.valid = 0;
+ WRSN_P4_MARK(q10_) WRSN_P4_SPAN(10, q4_, q10_)
             if (kind == 3) {
                 WRSN_PROF_MARK(tf0_)
+                WRSN_P4_MARK(q11_) WRSN_P4_CNT(7, 1)
                 int r = thread_fire(idx);
+                WRSN_P4_MARK(q12_) WRSN_P4_SPAN(6, q11_, q12_)
                 
                 if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; *pend_out = r; return r; }
                 // the same process usually owns the next event too (its hops at one instant, or its next timeout is
@@ -1784,26 +1832,32 @@ struct Sim {
         work = 0; budget = budget_;
         bool suspended = false, stopped = false;
         for (long guard = 0; guard < 8000000L; ++guard) {
+            WRSN_P4_MARK(r0_)
             { WRSN_PROF_T0
             if (lane == 0) {
                 int arg = 0, fl = 0; double tl = 0.0;
+                WRSN_P4_MARK(r1_)
                 int req = scalar_run(svc, use_limit, limit, &arg, &tl, &fl);
+                WRSN_P4_MARK(r2_) WRSN_P4_SPAN(0, r1_, r2_)
                 SREQ()[0] = req; SREQ()[1] = arg; SREQ()[3] = fl; SREQD()[0] = tl; SREQD()[1] = now; ((int64_t*)SREQD())[2] = seq;
             }
             __syncthreads();
             WRSN_PROF_ADD(0) WRSN_PROF_CNT(12, 1) }
             const int req = SREQ()[0], arg = SREQ()[1];
             now = wu(SREQD()[1]); seq = wu(((const int64_t*)SREQD())[2]);      // lane 0 advanced them while firing events
+            WRSN_P4_MARK(r3_) WRSN_P4_SPAN(11, r0_, r3_) WRSN_P4_CNT(20, 1)
             if (req == REQ_STOP) { stopped = true; break; }
             work += 16;
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
-            case REQ_GRID: { WRSN_PROF_T0 grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
+            case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { svc = precheck(arg); } break;
             case REQ_CONN: { conn_build(arg); } break;
             default: break;
             }
             __syncthreads();
+            WRSN_P4_MARK(r4_) if (req == REQ_GRID) { WRSN_P4_SPAN(14, r3_, r4_) } else if (req == REQ_PRECHECK) { WRSN_P4_SPAN(12, r3_, r4_) } else { WRSN_P4_SPAN(13, r3_, r4_) }
+            if (!HEAVY && need_heavy) { suspended = true; break; }   // the full variant goes on in front of this grid item
         }
         if (!stopped && !suspended) err = -10;               // the service loop ran out: the environment is stuck, report it (status < 0)
         __syncthreads();
@@ -1828,7 +1882,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     const int env = env0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= dp->B) return;
-    Sim<NPL> s;
+    Sim<NPL, true> s;
     s.bind(dp, env, lane, smem);
     const WrsnEnvConst* ec = s.EC();
     // NetworkIO.makeNetwork + Node.__init__ (Node.py:12-43) + t = 0 process start-up
@@ -1886,10 +1940,13 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     s.store(dp->snap, 0, 0);
 }
 
-template <int NPL>
+// `handoff`: 0 = the only environment launch of this call (full variant: blocking steps, resets);
+//            1 = lean launch of a budgeted step: an environment that meets a heavy service goes on the hand-off list;
+//            2 = continuation launch (full variant) over that list, block b takes its b-th entry.
+template <int NPL, bool HEAVY>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
                                                        const double* __restrict__ action, int auto_reset, int budget, long long epoch, int slots,
-                                                       const uint8_t* __restrict__ env_mask, WrsnStepOutDev out) {
+                                                       const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     // With a step budget the grid is 2 B blocks: the first B take the environments whose step is in flight (the long
@@ -1900,9 +1957,15 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     // only write during the launch is the owner's own (stamp = next launch, when its step suspends again), and that
     // value still tells block B + r to keep out; nothing the owner stores while it finishes is looked at by the other.
     int env = blockIdx.x; bool listed = false;
-    const int cur_l = (int)(epoch % 3), next_l = (int)((epoch + 1) % 3);
-    if (budget > 0 && !reset_call) {
-        if (blockIdx.x == 0 && lane == 0) dp->prio_n[(int)((epoch + 2) % 3)] = 0;   // the list the next launch fills (last read two launches ago)
+    const int cur_l = (int)(epoch % 3), next_l = (int)((epoch + 1) % 3), hand_l = (int)(epoch & 1);
+    if (handoff == 2) {
+        if ((int)blockIdx.x >= dp->heavy_n[hand_l]) return;
+        env = dp->heavy_list[(size_t)hand_l * dp->B + blockIdx.x];
+    } else if (budget > 0 && !reset_call) {
+        if (blockIdx.x == 0 && lane == 0) {
+            dp->prio_n[(int)((epoch + 2) % 3)] = 0;          // the list the next launch fills (last read two launches ago)
+            dp->heavy_n[hand_l ^ 1] = 0;                     // the hand-off list of the next call (last read by the continuation launch before this call)
+        }
         if ((int)blockIdx.x < dp->B) {
             if ((int)blockIdx.x >= dp->prio_n[cur_l]) return;
             env = dp->prio_list[(size_t)cur_l * dp->B + blockIdx.x]; listed = true;
@@ -1925,7 +1988,8 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     // a row nobody handles in this launch is not rendered and none of its outputs is touched
     if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) dp->render_agent[env] = -1; return; }
     int aid = -1, resume = 0;
-    if (!reset_call) {
+    if (handoff == 2) resume = 1;                          // handed over by the lean launch of this call: the step is in flight
+    else if (!reset_call) {
         aid = agent_id[env];
         if (budget > 0) {
             const long long stamp = dp->live.dyn[env].listed_for;
@@ -1944,7 +2008,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
         resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
-    Sim<NPL> s;
+    Sim<NPL, HEAVY> s;
     s.bind(dp, env, lane, smem);
 #ifdef WRSN_PROFILE
     for (int q_ = 0; q_ < 24; ++q_) s.prof_[q_] = 0;
@@ -1952,7 +2016,11 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     const long long wt0_ = wall_clock64();
 #endif
     const WrsnEnvConst* ec = s.EC();
-    s.load(do_reset ? dp->snap : dp->live);
+    { WRSN_P4_MARK(k0_) s.load(do_reset ? dp->snap : dp->live); WRSN_P4_MARK(k1_)
+#if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
+      s.prof_[16] += k1_ - k0_; s.prof_[18] += k0_ - kt0_;
+#endif
+    }
     if (do_reset) s.dirty = 7;                             // the snapshot goes to the live arrays in full
     const int64_t ticks0 = s.n_ticks;
     int terminal = 0, susp = 0;
@@ -2013,7 +2081,11 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             susp = s.run(false, 0.0, budget) ? 1 : 0;        // env.run(until=general_process)
             if (susp) { }
             else if (s.alive == 0) terminal = 1;             // WRSN.py:312-320
-            else { fit = s.min_fitness(); s.last_minfit = fit; }
+            else { WRSN_P4_MARK(k2_) fit = s.min_fitness(); s.last_minfit = fit; WRSN_P4_MARK(k3_)
+#if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
+                s.prof_[15] += k3_ - k2_;
+#endif
+            }
         }
         if (lane == 0 && susp) {                             // no request yet: status 4, the next launch goes on
             WrsnEnvDyn* dy = dp->live.dyn + env;
@@ -2025,7 +2097,10 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
             dp->render_agent[env] = -1;
-            if (budget > 0) {                                // first in line in the next launch
+            if (!HEAVY && s.need_heavy) {                    // the continuation launch of this call goes on with it
+                const int pos = atomicAdd(&dp->heavy_n[hand_l], 1);
+                dp->heavy_list[(size_t)hand_l * dp->B + pos] = env;
+            } else if (budget > 0) {                         // first in line in the next launch
                 const int pos = atomicAdd(&dp->prio_n[next_l], 1);
                 dp->prio_list[(size_t)next_l * dp->B + pos] = env;
                 dy->listed_for = epoch + 1;
@@ -2057,7 +2132,11 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             dp->render_agent[env] = agent;
         }
     }
-    s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp);
+    { WRSN_P4_MARK(k4_) s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp); WRSN_P4_MARK(k5_)
+#if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
+      s.prof_[17] += k5_ - k4_;
+#endif
+    }
     if (lane == 0 && reset_call) dp->live.dyn[env].listed_for = 0;   // a reset launch takes the environment off the in-flight list
     if (lane == 0 && !do_reset) dp->live.dyn[env].tot_ticks += s.n_ticks - ticks0;
 #ifdef WRSN_PROFILE

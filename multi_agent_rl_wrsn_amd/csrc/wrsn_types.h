@@ -104,6 +104,8 @@ struct WrsnDev {
     int32_t *prio_list;               // [3][B] environments whose step is in flight (step budget): launch e reads list e % 3, fills
                                       //        list (e + 1) % 3 and empties the count of list (e + 2) % 3 for the launch after it
     int32_t *prio_n;                  // [3]    their counts
+    int32_t *heavy_list;              // [2][B] hand-off of a budgeted step call: environments the lean launch stopped in front of a
+    int32_t *heavy_n;                 // [2]    heavy service (level BFS, routing rebuild, packet-exact second); list (call & 1)
     int32_t *render_agent;            // [B]    charger whose observation the launch's render pass draws (-1: none); written by the
                                       //        environment kernel for every row, including the rows it leaves untouched
 };
