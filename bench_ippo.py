@@ -1,0 +1,60 @@
+"""bench_ippo.py -- BASELINE.json configs[2]: 4096 environments x 200 nodes x 3 chargers, IPPO (alg_args/ippo.yaml) roll-out + train
+on one MI355X, environment time and policy time reported separately (SURVEY.md 8d "Config 3/4 note": the roll-out is
+policy-bound -- the UNet forward is ~5 GFLOP per decision against ~1e-3 GFLOP-equivalents of environment work).
+
+    python bench_ippo.py [--iters 1] [--envs 4096] [--batch-size 512]
+
+Prints ONE JSON line: per training iteration the wall time split into environment launches (VecWRSN.step incl. the
+observation), policy inference (UNet forward + sampling for every environment that carries a request), roll-out glue
+(transition buffers, density map -> action) and the PPO update; env-steps/s of the roll-out alone and with training.
+`python bench.py` stays the headline (random policy) measurement."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--nodes", type=int, default=200)
+    ap.add_argument("--batch-size", type=int, default=512)
+    ap.add_argument("--minibatch-size", type=int, default=64)
+    ap.add_argument("--updates", type=int, default=5)
+    ap.add_argument("--step-budget", type=int, default=1500)
+    ap.add_argument("--infer-chunk", type=int, default=512)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from multi_agent_rl_wrsn_amd import BatchedIPPO, VecWRSN, synth_scenario
+    torch.manual_seed(0); np.random.seed(0)
+    dev = torch.device("cuda", 0)
+    B, N, M = args.envs, args.nodes, 3
+    env = VecWRSN([synth_scenario(e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev))
+    algo = BatchedIPPO(dict(batch_size=args.batch_size, minibatch_size=args.minibatch_size, n_updates_per_iteration=args.updates), env,
+                       capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk)
+    c0 = env.counters(); t0 = time.perf_counter()
+    rows = algo.train(args.iters - 1)                          # train() runs iterations 0..n inclusive like the reference's loop (IPPO.py:220)
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    c1 = env.counters(); t = algo.timers; it = args.iters
+    steps = c1["env_steps"] - c0["env_steps"]
+    out = {"metric": "IPPO roll-out + train, 4096 envs x 200 nodes x 3 MC, 1 MI355X (BASELINE configs[2])", "iterations": it,
+           "config": {"workload": "%d envs x %d nodes x %d MC, UNet actor + CNN critic per charger, density-map actions, batch %d / minibatch %d / %d epochs" %
+                      (B, N, M, args.batch_size, args.minibatch_size, args.updates), "step_budget": args.step_budget},
+           "per_iteration_s": {"environment": t["env_s"] / it, "policy_inference": t["policy_s"] / it, "rollout_glue": t["glue_s"] / it, "ppo_update": t["train_s"] / it,
+                               "wall": wall / it},
+           "launches_per_iteration": t["launches"] / it, "requests_served": t["requests"], "env_steps": steps,
+           "env_steps_per_s_environment_only": steps / max(t["env_s"], 1e-9), "env_steps_per_s_rollout": steps / max(t["env_s"] + t["policy_s"] + t["glue_s"], 1e-9),
+           "env_steps_per_s_with_training": steps / wall, "transitions_per_agent": algo.buffers.counts(),
+           "last_rows": rows[-M:], "dtype": "f32 policy / f64 physics", "data": "synthetic"}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,43 @@ int wrsn_density_action(wrsn_t *h, const int32_t *agent_id, const double *dmap, 
  * buffer a data-parallel trainer all-gathers (one collective per rollout, no per-step reduction kernels). */
 int wrsn_rollout_table(wrsn_t *h, double *dst, int32_t zero_after);
 
+/* Roll-out bookkeeping of the asynchronous-agent batch: what controller/ippo/IPPO.py:119-156 (and controller/ppo/PPO.py:
+ * 115-152) keep in Python lists per environment, for B environments on the device.  All pointers are caller-owned DEVICE
+ * memory (torch tensors); the library keeps no roll-out state of its own.
+ *   pend_*   : per (environment, charger) the observation the charger last acted on, its raw policy output
+ *              (`input_action`: action_elems = 3, or G*G for density-map policies) and the log-probability;
+ *   the rest : per charger a list of `capacity` transitions (prev_state, input_action, log-prob, reward, state) plus the
+ *              environment index and env.now of every transition; count[m] = transitions appended for charger m so far
+ *              (it keeps counting past `capacity`: the excess is dropped, not stored). */
+typedef struct wrsn_transition_buffers {
+    int32_t capacity, action_elems;
+    float   *pend_state;      /* [B, M, 4, G, G] */
+    float   *pend_action;     /* [B, M, action_elems] */
+    float   *pend_logp;       /* [B, M] */
+    uint8_t *pend_valid;      /* [B, M]  1: the charger has acted in the running episode */
+    float   *state;           /* [M, capacity, 4, G, G]  request["prev_state"]   (IPPO.py:150) */
+    float   *action;          /* [M, capacity, action_elems]  request["input_action"] (IPPO.py:151) */
+    float   *next_state;      /* [M, capacity, 4, G, G]  request["state"]        (IPPO.py:152) */
+    float   *reward;          /* [M, capacity]           request["reward"]       (IPPO.py:153) */
+    float   *logp;            /* [M, capacity]           log_probs_pre[agent]    (IPPO.py:154) */
+    double  *now;             /* [M, capacity]           env.now at the return */
+    int32_t *env;             /* [M, capacity]           environment of the transition */
+    int32_t *count;           /* [M] */
+} wrsn_transition_buffers;
+
+/* The chargers named by agent_id (DEVICE int32 [B], < 0: row skipped) are about to be given `action` (DEVICE float
+ * [B, action_elems], the policy's raw output) chosen with log-probability logp (DEVICE float [B]) on observation obs (DEVICE
+ * float [B,4,G,G]): remember them as pending (IPPO.py:141-142).  Call before wrsn_step with the same agent_id. */
+int wrsn_rollout_record(wrsn_t *h, const wrsn_transition_buffers *buf, const int32_t *agent_id, const float *action,
+                        const float *logp, const float *obs);
+
+/* After wrsn_step / wrsn_reset wrote `out` (every field non-NULL): rows whose WRSN.step completed in that launch and returned a
+ * charger with a pending action append one transition to that charger's list (IPPO.py:146-155: a charger that has not acted yet
+ * in the episode is skipped); terminal rows and (auto-)reset rows discard what was pending (IPPO.py:144-145); rows the launch left
+ * untouched (agent -2 / masked out) or whose step is still in flight (status 4) are skipped -- the library remembers per row what
+ * the last environment launch did, so a request is consumed once however often this is called. */
+int wrsn_rollout_collect(wrsn_t *h, const wrsn_transition_buffers *buf, const wrsn_step_out *out);
+
 /* Render get_state(agent) for arbitrary agents (DEVICE int32 [B], < 0 = skip) into obs (DEVICE). */
 int wrsn_render(wrsn_t *h, const int32_t *agent_id, float *obs);
 

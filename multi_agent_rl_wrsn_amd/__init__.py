@@ -8,6 +8,8 @@ from .scenario import (DEFAULT_MC_SPEC, DEFAULT_NODE_SPEC, Scenario, load_mc_yam
 from .sharding import RolloutStats, init_distributed, shard_range  # noqa: F401
 from .vec_env import VecWRSN  # noqa: F401
 from .wrsn import WRSN  # noqa: F401
+from .ippo import BatchedIPPO, PPOLearner, TransitionBuffers, build_networks, select_batch  # noqa: F401
 
 __all__ = ["Scenario", "load_scenario_yaml", "load_mc_yaml", "synth_scenario", "synth_batch", "scenario_from_golden",
-           "DEFAULT_NODE_SPEC", "DEFAULT_MC_SPEC", "VecWRSN", "WRSN", "RolloutStats", "init_distributed", "shard_range"]
+           "DEFAULT_NODE_SPEC", "DEFAULT_MC_SPEC", "VecWRSN", "WRSN", "RolloutStats", "init_distributed", "shard_range",
+           "BatchedIPPO", "PPOLearner", "TransitionBuffers", "build_networks", "select_batch"]

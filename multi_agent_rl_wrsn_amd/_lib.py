@@ -25,7 +25,7 @@ ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max"
 
 # every entry point include/wrsn_hip.h declares
 EXPORTS = ("wrsn_create", "wrsn_destroy", "wrsn_set_stream", "wrsn_set_scenario", "wrsn_reset", "wrsn_step",
-           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
+           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
            "wrsn_last_error",
            "wrsn_version")
 
@@ -49,6 +49,12 @@ class WrsnMcSpec(C.Structure):
 class WrsnStepOut(C.Structure):
     _fields_ = [("agent_id", C.c_void_p), ("reward", C.c_void_p), ("terminal", C.c_void_p), ("now", C.c_void_p),
                 ("obs", C.c_void_p), ("status", C.c_void_p)]
+
+
+class WrsnTransitionBuffers(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("action_elems", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("pend_state", "pend_action", "pend_logp", "pend_valid", "state", "action", "next_state",
+                                          "reward", "logp", "now", "env", "count")]
 
 
 class WrsnError(RuntimeError):
@@ -79,6 +85,10 @@ def bind(lib):
     lib.wrsn_density_action.restype = C.c_int
     lib.wrsn_rollout_table.argtypes = [vp, vp, C.c_int32]
     lib.wrsn_rollout_table.restype = C.c_int
+    lib.wrsn_rollout_record.argtypes = [vp, C.POINTER(WrsnTransitionBuffers), vp, vp, vp, vp]
+    lib.wrsn_rollout_record.restype = C.c_int
+    lib.wrsn_rollout_collect.argtypes = [vp, C.POINTER(WrsnTransitionBuffers), C.POINTER(WrsnStepOut)]
+    lib.wrsn_rollout_collect.restype = C.c_int
     lib.wrsn_render.argtypes = [vp, vp, vp]
     lib.wrsn_render.restype = C.c_int
     lib.wrsn_peek.argtypes = [vp, C.c_int32, vp]
@@ -198,6 +208,14 @@ class RawHandle:
 
     def rollout_table(self, dst_ptr, zero_after=False):
         check(self.lib, self.lib.wrsn_rollout_table(self._h, C.c_void_p(dst_ptr), 1 if zero_after else 0))
+
+    def rollout_record(self, buffers, agent_ptr, action_ptr, logp_ptr, obs_ptr):
+        check(self.lib, self.lib.wrsn_rollout_record(self._h, C.byref(buffers), C.c_void_p(agent_ptr), C.c_void_p(action_ptr),
+                                                     C.c_void_p(logp_ptr), C.c_void_p(obs_ptr)))
+
+    def rollout_collect(self, buffers, **out_ptrs):
+        o = self._out(**out_ptrs)
+        check(self.lib, self.lib.wrsn_rollout_collect(self._h, C.byref(buffers), C.byref(o)))
 
     def render(self, agent_ptr, obs_ptr):
         check(self.lib, self.lib.wrsn_render(self._h, C.c_void_p(agent_ptr), C.c_void_p(obs_ptr)))

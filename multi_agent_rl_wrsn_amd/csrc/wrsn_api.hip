@@ -13,6 +13,7 @@
 
 #include "../../include/wrsn_hip.h"
 #include "wrsn_sim.h"
+#include "wrsn_rollout.h"
 
 namespace {
 
@@ -225,6 +226,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.prio_list, 3 * B))) break;
         if ((rc = dalloc(h, &d.prio_n, 3))) break;
         if ((rc = dalloc(h, &d.render_agent, B))) break;
+        if ((rc = dalloc(h, &d.row_state, B))) break;
         if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
         if ((rc = dalloc(h, &d.heavy_n, 2))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
@@ -358,6 +360,38 @@ int wrsn_rollout_table(wrsn_t* h, double* dst, int32_t zero_after) {
     if (!h->scenario_set) return fail(WRSN_ERR_STATE, "wrsn_set_scenario has not been called");
     WRSN_ON_DEVICE(h);
     hipLaunchKernelGGL(wrsn_rollout_kernel, dim3((h->dev.B + 255) / 256), dim3(256), 0, h->stream, h->dev, dst, (int)zero_after);
+    HIPCHK(hipGetLastError());
+    return WRSN_OK;
+}
+
+static int tr_buffers(const wrsn_transition_buffers* b, WrsnTrBuffers* t) {
+    if (!b || b->capacity < 1 || b->action_elems < 1 || !b->pend_state || !b->pend_action || !b->pend_logp || !b->pend_valid || !b->state ||
+        !b->action || !b->next_state || !b->reward || !b->logp || !b->now || !b->env || !b->count)
+        return fail(WRSN_ERR_ARG, "wrsn_transition_buffers: null pointer or empty geometry");
+    t->capacity = b->capacity; t->action_elems = b->action_elems;
+    t->pend_state = b->pend_state; t->pend_action = b->pend_action; t->pend_logp = b->pend_logp; t->pend_valid = b->pend_valid;
+    t->state = b->state; t->action = b->action; t->next_state = b->next_state; t->reward = b->reward; t->logp = b->logp;
+    t->now = b->now; t->env = b->env; t->count = b->count;
+    return 0;
+}
+
+int wrsn_rollout_record(wrsn_t* h, const wrsn_transition_buffers* buf, const int32_t* agent_id, const float* action, const float* logp,
+                        const float* obs) {
+    if (!h || !agent_id || !action || !logp || !obs) return fail(WRSN_ERR_ARG, "null argument");
+    WrsnTrBuffers t; int rc = tr_buffers(buf, &t); if (rc) return rc;
+    WRSN_ON_DEVICE(h);
+    hipLaunchKernelGGL(wrsn_tr_record_kernel, dim3(h->dev.B), dim3(256), 0, h->stream, h->dev.B, h->dev.M, h->dev.G, t, agent_id, action, logp, obs);
+    HIPCHK(hipGetLastError());
+    return WRSN_OK;
+}
+
+int wrsn_rollout_collect(wrsn_t* h, const wrsn_transition_buffers* buf, const wrsn_step_out* out) {
+    if (!h || !out || !out->agent_id || !out->reward || !out->terminal || !out->now || !out->status || !out->obs)
+        return fail(WRSN_ERR_ARG, "wrsn_rollout_collect needs every wrsn_step_out field");
+    WrsnTrBuffers t; int rc = tr_buffers(buf, &t); if (rc) return rc;
+    WRSN_ON_DEVICE(h);
+    hipLaunchKernelGGL(wrsn_tr_collect_kernel, dim3(h->dev.B), dim3(256), 16, h->stream, h->dev.B, h->dev.M, h->dev.G, t, out->agent_id,
+                       out->reward, out->now, h->dev.row_state, out->obs);
     HIPCHK(hipGetLastError());
     return WRSN_OK;
 }

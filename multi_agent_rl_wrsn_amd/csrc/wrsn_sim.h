@@ -1986,7 +1986,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     if (env < 0 || env >= dp->B) return;
     bool do_reset = reset_call != 0;
     // a row nobody handles in this launch is not rendered and none of its outputs is touched
-    if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) dp->render_agent[env] = -1; return; }
+    if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
     int aid = -1, resume = 0;
     if (handoff == 2) resume = 1;                          // handed over by the lean launch of this call: the step is in flight
     else if (!reset_call) {
@@ -1998,13 +1998,13 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
                 if (aid == -2) {                           // left untouched: stays in flight, stays listed
                     if (lane == 0) {
                         const int pos = atomicAdd(&dp->prio_n[next_l], 1); dp->prio_list[(size_t)next_l * dp->B + pos] = env;
-                        dp->live.dyn[env].listed_for = epoch + 1; dp->render_agent[env] = -1;
+                        dp->live.dyn[env].listed_for = epoch + 1; dp->render_agent[env] = -1; dp->row_state[env] = 0;
                     }
                     return;
                 }
             } else if (stamp >= epoch) return;             // listed for this launch: the listed block owns it
         }
-        if (aid == -2) { if (lane == 0) dp->render_agent[env] = -1; return; }
+        if (aid == -2) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
         resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
@@ -2036,7 +2036,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = (s.alive == 1) ? 0 : 1;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = reset_call ? 0 : 3;
-            dp->render_agent[env] = agent;
+            dp->render_agent[env] = agent; dp->row_state[env] = 2;
         }
     } else {
         // ------------------------------------------------------ WRSN.step
@@ -2096,7 +2096,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = 0;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
-            dp->render_agent[env] = -1;
+            dp->render_agent[env] = -1; dp->row_state[env] = 3;
             if (!HEAVY && s.need_heavy) {                    // the continuation launch of this call goes on with it
                 const int pos = atomicAdd(&dp->heavy_n[hand_l], 1);
                 dp->heavy_list[(size_t)hand_l * dp->B + pos] = env;
@@ -2129,7 +2129,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.terminal) out.terminal[env] = (uint8_t)terminal;
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = status;
-            dp->render_agent[env] = agent;
+            dp->render_agent[env] = agent; dp->row_state[env] = terminal ? 4 : 1;
         }
     }
     { WRSN_P4_MARK(k4_) s.store(dp->live, terminal, (do_reset || susp) ? 0 : 1, susp); WRSN_P4_MARK(k5_)

@@ -106,6 +106,8 @@ struct WrsnDev {
     int32_t *prio_n;                  // [3]    their counts
     int32_t *heavy_list;              // [2][B] hand-off of a budgeted step call: environments the lean launch stopped in front of a
     int32_t *heavy_n;                 // [2]    heavy service (level BFS, routing rebuild, packet-exact second); list (call & 1)
+    int32_t *row_state;               // [B]    what the last environment launch did with the row: 0 left untouched, 1 WRSN.step completed
+                                      //        (fresh request), 2 reset / auto-reset request, 3 step still in flight, 4 terminal return
     int32_t *render_agent;            // [B]    charger whose observation the launch's render pass draws (-1: none); written by the
                                       //        environment kernel for every row, including the rows it leaves untouched
 };

@@ -23,6 +23,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 
+struct alignas(16) float4 { float x, y, z, w; };
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct emu_idx { unsigned x, y, z; };
 extern emu_idx threadIdx, blockIdx, blockDim, gridDim;

@@ -490,3 +490,83 @@ def test_step_budget_never_runs_an_environment_twice_per_launch():
     c = env.counters()
     assert c["env_steps"] == int(want[:, M + 2].sum())
     env.close()
+
+
+def test_transition_buffers_equal_the_reference_bookkeeping_on_device():
+    """f2: the device-side transition buffers of a batched roll-out (auto-reset, step budget) hold exactly what the reference's
+    list bookkeeping (controller/ippo/IPPO.py:137-155, restated in tests/test_ippo.py) collects from B = 1 environments."""
+    torch = _torch()
+    from multi_agent_rl_wrsn_amd import TransitionBuffers, VecWRSN, synth_scenario
+    from test_ippo import _policy, reference_bookkeeping
+    B, M, K, CAP = 6, 3, 30, 128
+    scs = [synth_scenario(4300 + e, 100, 80) for e in range(B)]
+    env = VecWRSN(scs, None, M, auto_reset=True, step_budget=200)
+    buf = TransitionBuffers(env, CAP, 3)
+    r = env.reset(); env.synchronize()
+    n_dec = np.zeros(B, dtype=int)
+    for it in range(600):
+        ids = r["agent_id"].cpu().numpy().copy()
+        act = np.zeros((B, 3), np.float32); lp = np.zeros(B, np.float32)
+        for e in range(B):
+            if ids[e] >= 0 and n_dec[e] < K:
+                act[e], lp[e] = _policy(e, n_dec[e]); n_dec[e] += 1
+            elif ids[e] >= 0:
+                ids[e] = -2
+        tid = torch.tensor(ids, dtype=torch.int32)
+        buf.record(tid, torch.from_numpy(act), torch.from_numpy(lp))
+        r = env.step(tid, torch.from_numpy(act).double())
+        buf.collect(); buf.collect()                          # a request is consumed once
+        env.synchronize()
+        if (n_dec >= K).all() and not bool((r["status"] == 4).any()):
+            break
+    counts = buf.counts()
+    want = [[] for _ in range(M)]
+    for e in range(B):
+        one = VecWRSN([scs[e]], None, M)
+        def req(rr):
+            one.synchronize()
+            return dict(agent_id=int(rr["agent_id"][0]), state=rr["state"][0].cpu().numpy().copy(), reward=float(rr["reward"][0]), terminal=bool(rr["terminal"][0]),
+                        now=float(rr["now"][0]), policy=lambda n, e=e: _policy(e, n))
+        per_agent = reference_bookkeeping(lambda a, action: req(one.step(torch.tensor([a]), torch.tensor(np.asarray(action, np.float64)[None]))),
+                                          lambda: req(one.reset()), M, K)
+        one.close()
+        for a in range(M):
+            want[a] += [(e,) + t for t in per_agent[a]]
+    st = buf.state.cpu().numpy(); nx = buf.next_state.cpu().numpy(); ac = buf.action.cpu().numpy(); rw = buf.reward.cpu().numpy()
+    lg = buf.logp.cpu().numpy(); nw = buf.now.cpu().numpy(); en = buf.env_index.cpu().numpy()
+    total = 0
+    for a in range(M):
+        n = counts[a]
+        assert n == len(want[a]) and n <= CAP, (a, n, len(want[a]))
+        got = sorted(range(n), key=lambda q: (en[a, q], nw[a, q], lg[a, q]))
+        ref = sorted(want[a], key=lambda t: (t[0], t[6], t[3]))
+        for q, t in zip(got, ref):
+            assert en[a, q] == t[0] and nw[a, q] == t[6] and lg[a, q] == t[3]
+            assert np.array_equal(st[a, q], t[1]) and np.array_equal(ac[a, q], t[2]) and rw[a, q] == np.float32(t[4]) and np.array_equal(nx[a, q], t[5])
+        total += n
+    assert total > 40
+    env.close()
+
+
+def test_batched_ippo_rollout_and_update_smoke():
+    """configs[2] at a toy size: BatchedIPPO (UNet actor / CNN critic per charger, density-map actions) rolls out a batch of
+    environments into the device buffers, selects the batch like the reference and runs the PPO update."""
+    torch = _torch()
+    from multi_agent_rl_wrsn_amd import BatchedIPPO, VecWRSN, synth_scenario
+    torch.manual_seed(0); np.random.seed(0)
+    B, M = 48, 3
+    env = VecWRSN([synth_scenario(9100 + e, 200, 200) for e in range(B)], None, M, auto_reset=True, step_budget=1500)
+    algo = BatchedIPPO(dict(batch_size=16, minibatch_size=8, n_updates_per_iteration=1), env, capacity=64)
+    batches = algo.roll_out(max_launches=60)
+    assert min(algo.buffers.counts()) >= 16
+    for a in range(M):
+        b = batches[a]
+        assert b["states"].shape == (16, 4, 100, 100) and b["actions"].shape == (16, 100, 100) and b["returns"].shape == (16,)
+        assert torch.equal(b["returns"], b["advantages"] + b["values"]) or torch.allclose(b["returns"], b["rewards"], atol=1e-6)
+        before = [p.detach().clone() for p in algo.actors[a].parameters()]
+        stats = algo.update(a, b)
+        assert all(np.isfinite(v) for v in stats)
+        assert any(not torch.equal(p0, p1) for p0, p1 in zip(before, algo.actors[a].parameters()))
+    t = algo.timers
+    assert t["env_s"] > 0 and t["policy_s"] > 0 and t["launches"] >= 1
+    env.close()

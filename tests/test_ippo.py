@@ -1,0 +1,211 @@
+"""f2 / f4 on the CPU: policy networks and trainer arithmetic against vectors generated from the reference's own modules
+(tests/golden_policy/policy_nets.npz, script oracle/refharness/gen_policy_golden.py), the batch selection, the device-side
+transition bookkeeping (emulated kernels) against the reference's list bookkeeping restated from controller/ippo/IPPO.py:137-155,
+and the data-parallel gradient exchange on a world-2 gloo group."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden_policy", "policy_nets.npz")
+
+
+def formula_fill(module):
+    """the fill of oracle/refharness/gen_policy_golden.py"""
+    import torch
+    with torch.no_grad():
+        for name, t in list(module.named_parameters()) + list(module.named_buffers()):
+            if not t.dtype.is_floating_point:
+                continue
+            k = (zlib.crc32(name.encode()) % 1000) / 100.0
+            v = 0.05 * torch.sin(0.37 * torch.arange(t.numel(), dtype=torch.float64) + k)
+            if name.endswith("bn.weight") or name.endswith("running_var"):
+                v = v + 1.0
+            t.copy_(v.reshape(t.shape).to(t.dtype))
+
+
+def test_networks_match_the_reference_modules():
+    import torch
+    from multi_agent_rl_wrsn_amd import build_networks
+    z = np.load(GOLD)
+    torch.manual_seed(0); torch.set_num_threads(4)
+    UNet, CNNCritic = build_networks(100)
+    actor, critic = UNet(), CNNCritic()
+    # same state_dict keys and shapes: reference checkpoints (actor.pth / critic.pth, IPPO.py:296-309) load unchanged
+    assert [n for n in actor.state_dict()] == list(z["actor_names"]) and [str(tuple(v.shape)) for v in actor.state_dict().values()] == list(z["actor_shapes"])
+    assert [n for n in critic.state_dict()] == list(z["critic_names"]) and [str(tuple(v.shape)) for v in critic.state_dict().values()] == list(z["critic_shapes"])
+    formula_fill(actor); formula_fill(critic)
+    x = torch.from_numpy(z["x"])
+    actor.train()
+    with torch.no_grad():
+        mean, log_std = actor(x)
+        value = critic(x)
+    assert np.allclose(mean.numpy(), z["actor_mean"], rtol=1e-4, atol=1e-5)
+    assert np.allclose(log_std.detach().numpy(), z["actor_log_std"], rtol=0, atol=1e-7)
+    assert np.allclose(value.numpy(), z["critic_value"], rtol=1e-4, atol=1e-6)
+
+
+def test_cal_rt_adv_matches_the_reference_function():
+    import torch
+    from multi_agent_rl_wrsn_amd import PPOLearner
+    z = np.load(GOLD)
+    T = len(z["rt_rewards"])
+    table = {float(i): float(v) for i, v in enumerate(z["rt_values"])}; table.update({float(i) + 100: float(v) for i, v in enumerate(z["rt_next_values"])})
+    lr = PPOLearner(dict(gamma=0.99, gae=True, gae_lambda=0.95), 1, 12, "cpu")
+    lr._values = lambda id, s: torch.tensor([table[float(v)] for v in s])
+    states = torch.arange(T, dtype=torch.float32)
+    ret, adv, v = lr.cal_rt_adv(0, states, torch.from_numpy(z["rt_rewards"]), states + 100, torch.from_numpy(z["rt_terminals"]))
+    assert np.allclose(ret.numpy(), z["rt_returns_gae1"], rtol=1e-6, atol=1e-7) and np.allclose(adv.numpy(), z["rt_adv_gae1"], rtol=1e-6, atol=1e-7)
+    # with the flags the roll-out really stores (all False, IPPO.py:144-155) returns are the rewards
+    ret0, adv0, _ = lr.cal_rt_adv(0, states, torch.from_numpy(z["rt_rewards"]), states + 100, torch.zeros(T))
+    assert np.allclose(ret0.numpy(), z["rt_rewards"], atol=1e-7) and np.allclose(adv0.numpy(), z["rt_rewards"] - z["rt_values"], atol=1e-7)
+    # the plain (gae: False) branch of the reference raises on every non-empty input; so does this one
+    assert str(z["rt_error_gae0"]) == "IndexError"
+    lr.gae = False
+    with pytest.raises(IndexError):
+        lr.cal_rt_adv(0, states, torch.from_numpy(z["rt_rewards"]), states + 100, torch.zeros(T))
+
+
+def test_select_batch_is_the_reference_selection():
+    from multi_agent_rl_wrsn_amd import select_batch
+    rng = np.random.RandomState(3)
+    rewards = rng.randn(700)
+    np.random.seed(11)
+    got = select_batch(rewards, 512)
+    # IPPO.py:193-200, statement for statement
+    np.random.seed(11)
+    mean = np.mean(rewards)
+    abs_diff = np.abs(rewards - mean)
+    indices = np.argsort(abs_diff)
+    selected_num = int(512 / 2.0)
+    random_num = 512 - selected_num
+    want = np.concatenate((indices[-selected_num:], np.random.choice(len(rewards) - selected_num, size=random_num, replace=False)))
+    assert np.array_equal(got, want) and len(got) == 512
+
+
+def _policy(e, n):
+    """deterministic stand-in for the actor: action 3-vector and log-prob of environment e's n-th decision"""
+    r = np.random.RandomState(1000 * e + n)
+    return r.rand(3).astype(np.float32), np.float32(-0.01 * n - e)
+
+
+def reference_bookkeeping(step, reset, n_agent, n_decisions):
+    """controller/ippo/IPPO.py:137-155 for ONE environment: returns per agent the list of
+    (prev_state, input_action, log_prob, reward, state, now).  `reset()` / `step(agent, action)` return request dicts."""
+    out = [[] for _ in range(n_agent)]
+    done = 0
+    while done < n_decisions:
+        request = reset()
+        pre = [None] * n_agent; prev_state = [None] * n_agent; prev_action = [None] * n_agent
+        while done < n_decisions:
+            a = request["agent_id"]
+            action, log_prob = request["policy"](done); done += 1
+            pre[a] = log_prob; prev_state[a] = request["state"]; prev_action[a] = action
+            request = step(a, action)
+            if request["terminal"]:
+                break
+            b = request["agent_id"]
+            if pre[b] is None:
+                continue
+            out[b].append((prev_state[b], prev_action[b], pre[b], request["reward"], request["state"], request["now"]))
+    return out
+
+
+def test_emulated_transition_buffers_equal_the_reference_bookkeeping():
+    """wrsn_rollout_record / wrsn_rollout_collect (csrc/wrsn_rollout.h, emulated) over a batch with auto-reset and a step
+    budget == the reference's per-environment list bookkeeping on single environments."""
+    import ctypes as C
+    from emu_env import EmuVec
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, _lib, synth_scenario
+    B, M, G, CAP, K = 3, 2, 12, 64, 28
+    scs = [synth_scenario(300 + e, 70, 60) for e in range(B)]
+    ev = EmuVec(scs, DEFAULT_MC_SPEC, M, map_size=G)
+    ev.h.set_step_budget(60)
+    S = 4 * G * G
+    arrs = dict(pend_state=np.zeros((B, M, S), np.float32), pend_action=np.zeros((B, M, 3), np.float32), pend_logp=np.zeros((B, M), np.float32),
+                pend_valid=np.zeros((B, M), np.uint8), state=np.zeros((M, CAP, S), np.float32), action=np.zeros((M, CAP, 3), np.float32),
+                next_state=np.zeros((M, CAP, S), np.float32), reward=np.zeros((M, CAP), np.float32), logp=np.zeros((M, CAP), np.float32),
+                now=np.zeros((M, CAP), np.float64), env=np.zeros((M, CAP), np.int32), count=np.zeros(M, np.int32))
+    buf = _lib.WrsnTransitionBuffers(CAP, 3, *[arrs[k].ctypes.data for k in ("pend_state", "pend_action", "pend_logp", "pend_valid", "state", "action",
+                                                                            "next_state", "reward", "logp", "now", "env", "count")])
+    ev.reset()
+    n_dec = np.zeros(B, dtype=int)
+    for it in range(400):
+        ids = ev.agent_id.copy()
+        act = np.zeros((B, 3), np.float32); lp = np.zeros(B, np.float32)
+        for e in range(B):
+            if ids[e] >= 0 and n_dec[e] < K:
+                act[e], lp[e] = _policy(e, n_dec[e]); n_dec[e] += 1
+            elif ids[e] >= 0:
+                ids[e] = -2                                    # this environment has had its K decisions
+        ev.h.rollout_record(buf, ids.ctypes.data, act.ctypes.data, lp.ctypes.data, ev.obs.ctypes.data)
+        ev.step(ids, act.astype(np.float64), auto_reset=True)
+        ev.h.rollout_collect(buf, **ev._ptrs(True))
+        if (n_dec >= K).all() and not (ev.status == 4).any():
+            break
+    # the same decisions, one environment at a time, with the reference's bookkeeping
+    want = [[] for _ in range(M)]
+    for e in range(B):
+        one = EmuVec([scs[e]], DEFAULT_MC_SPEC, M, map_size=G)
+        def req():
+            return dict(agent_id=int(one.agent_id[0]), state=one.obs[0].reshape(-1).copy(), reward=float(one.reward[0]), terminal=bool(one.terminal[0]),
+                        now=float(one.now[0]), policy=lambda n, e=e: _policy(e, n))
+        def reset():
+            one.reset(); return req()
+        def step(a, action):
+            one.step([a], np.asarray(action, np.float64)[None]); return req()
+        per_agent = reference_bookkeeping(step, reset, M, K)
+        for a in range(M):
+            want[a] += [(e,) + t for t in per_agent[a]]
+    for a in range(M):
+        n = int(arrs["count"][a])
+        assert n == len(want[a]) and 0 < n <= CAP
+        got = sorted(range(n), key=lambda q: (arrs["env"][a, q], arrs["now"][a, q], arrs["logp"][a, q]))
+        ref = sorted(want[a], key=lambda t: (t[0], t[6], t[3]))
+        for q, t in zip(got, ref):
+            assert arrs["env"][a, q] == t[0] and arrs["now"][a, q] == t[6]
+            assert np.array_equal(arrs["state"][a, q], t[1]) and np.array_equal(arrs["action"][a, q], t[2]) and arrs["logp"][a, q] == t[3]
+            assert arrs["reward"][a, q] == np.float32(t[4]) and np.array_equal(arrs["next_state"][a, q], t[5])
+
+
+def _dp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multi_agent_rl_wrsn_amd import PPOLearner
+    torch.manual_seed(100 + rank)                              # different initial weights per rank: the broadcast must equalise them
+    G, n = 12, 8
+    lr = PPOLearner(dict(batch_size=n, minibatch_size=4, n_updates_per_iteration=2, lr=1e-3), 1, G, "cpu")
+    p0 = torch.cat([p.detach().reshape(-1) for p in list(lr.actors[0].parameters()) + list(lr.critics[0].parameters())]).clone()
+    g = torch.Generator().manual_seed(7 + rank)                # a different local batch per rank
+    batch = dict(states=torch.rand((n, 4, G, G), generator=g), actions=torch.randn((n, G, G), generator=g), log_probs=torch.randn(n, generator=g) - 150.0,
+                 advantages=torch.randn(n, generator=g), returns=torch.randn(n, generator=g), values=torch.randn(n, generator=g))
+    order = np.random.RandomState(3)
+    lr.update(0, batch, shuffle=order.shuffle)
+    p1 = torch.cat([p.detach().reshape(-1) for p in list(lr.actors[0].parameters()) + list(lr.critics[0].parameters())])
+    q.put((rank, p0.numpy(), p1.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo_world2():
+    """f4: after the rank-0 broadcast and two epochs of minibatch updates with ONE all-reduce of the flattened actor + critic
+    gradients per minibatch, both ranks hold identical parameters (they saw different batches), and the parameters moved."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps: p.start()
+    res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
+    for p in ps: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in ps)
+    (_, a0, a1), (_, b0, b1) = res
+    assert np.array_equal(a0, b0)                                # broadcast from rank 0
+    assert np.array_equal(a1, b1)                                # identical updates on both ranks
+    assert np.abs(a1 - a0).max() > 1e-5
