@@ -53,7 +53,7 @@ def main():
            "env_steps_per_s_environment_only": steps / max(t["env_s"], 1e-9), "env_steps_per_s_rollout": steps / max(t["env_s"] + t["policy_s"] + t["glue_s"], 1e-9),
            "env_steps_per_s_with_training": steps / wall, "transitions_per_agent": algo.buffers.counts(),
            "last_rows": rows[-M:], "dtype": "f32 policy / f64 physics", "data": "synthetic"}
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out, default=float), flush=True)
 
 
 if __name__ == "__main__":

@@ -113,6 +113,10 @@ def load():
     """Load the in-tree HIP library.  Fails loudly when it has not been built."""
     global _lib
     if _lib is None:
+        alt = os.environ.get("WRSN_HIP_LIB")                   # diagnostic: another BUILD OF THE SAME HIP library (A/B timing runs)
+        if alt:
+            _lib = bind(C.CDLL(alt))
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

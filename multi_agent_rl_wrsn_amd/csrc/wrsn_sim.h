@@ -2424,6 +2424,10 @@ struct WrsnFalse { static constexpr bool value = false; };
 #ifndef WRSN_V16F_DEFINED
 typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
 #endif
+#ifndef WRSN_WAVE_FIRST_DEFINED
+// value of the first active lane for the whole wave (the CPU emulator of tests/emu supplies its own rendezvous)
+WDEV int wrsn_wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
     extern __shared__ double smem[];
     const int env = blockIdx.x, tid = threadIdx.x;
@@ -2433,17 +2437,26 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     const int N = ec->n_node, NP = d.NP, G = d.G, M = d.M;
     const size_t nb = (size_t)env * NP;
     const WrsnEnvDyn* dy = d.live.dyn + env;
-    double* pc = smem;                                     // [NP + 2 CH][2]  cx, cy of every node
-    float* wf = (float*)(pc + 2 * (NP + 2 * WRSN_OBS_CH)); // [NP + 2 CH] weight as float32 (0: dead / padding)
-    float* bbox = wf + NP + 2 * WRSN_OBS_CH;               // [NP / CH + 2][4] x / y range of the weighted nodes of a chunk
-    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // four wave-private (A [CH][32], B [CH][128]) buffer pairs
+    // node coordinates (normalised to the frame) as float32 OFFSETS from the centre of each 32-row band (x) and of each 32-column
+    // tile (y): the differences the Gaussians need are then float32 subtractions of small numbers (|.| < 0.7, error ~3e-8) instead
+    // of a float64 subtraction and a conversion per element
+    const int NS = NP + 2 * WRSN_OBS_CH;
+    float* pxb = (float*)smem;                             // [3][NS]  x - (32 w + 16) / G
+    float* pyt = pxb + 3 * NS;                             // [4][NS]  y - (32 t + 16) / G
+    float* wf = pyt + 4 * NS;                              // [NS] weight as float32 (0: dead / padding)
+    float* bbox = wf + NS;                                 // [NP / CH + 2][4] x / y range of the weighted nodes of a chunk
+    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // three wave-private (A [CH][32], B [CH][128]) buffer pairs, then the term rows
     const double fx0 = ec->frame[0], fy0 = ec->frame[2];
     const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
     const double unit = 1.0 / G;
     const double hX = ec->charging_range / W, hY = ec->charging_range / H;
     const float inv2hx = (float)(-1.0 / (2.0 * hX * hX)), inv2hy = (float)(-1.0 / (2.0 * hY * hY));
     float* out = obs + (size_t)env * 4 * G * G;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: `band` / `isx` become scalar branches
+    // Role of a wave: 0..2 = the 32-row band of map 1 it computes on the matrix cores, 3 = the store wave (rows 96.. of map 1 on the
+    // VALU, then maps 2..4).  The roles rotate with the block index so that the (matrix-core-free) store waves of the blocks resident
+    // on a CU do not all sit on the same SIMD.
+    const int hw_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = (hw_wave + (int)((blockIdx.x ^ (blockIdx.x >> 3) ^ (blockIdx.x >> 8)) & 3u)) & 3;   // wave-uniform
     const int l = tid & 63, half = l >> 5, l31 = l & 31;
     const int row0 = 32 * wave;                            // this wave's band of map rows
     const bool band = row0 < G;
@@ -2453,6 +2466,13 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
 #else
 #define WRSN_OBS_STAMP(k)
 #endif
+    // the chargers of the environment go to LDS in one coalesced round trip (the term rows below read a dozen of their fields);
+    // they sit in the first wave buffer, which is not in use before the second barrier
+    WrsnAgent* sag = (WrsnAgent*)A;
+    {
+        const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)sag;
+        for (int w = tid; w < M * (int)(sizeof(WrsnAgent) / 8); w += 256) la[w] = ga[w];
+    }
     {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
         const double a_b2 = ec->alpha / (ec->beta * ec->beta), thr = ec->threshold, span = ec->capacity - ec->threshold;
         for (int n = tid; n < NP; n += 256) {
@@ -2465,9 +2485,17 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
                 cx = (px - fx0) / W; cy = (py - fy0) / H;
                 w = (csv / a_b2) / ((en - thr) / span);
             }
-            pc[n * 2 + 0] = cx; pc[n * 2 + 1] = cy; wf[n] = (float)w;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) pxb[w * NS + n] = (float)(cx - (32 * w + 16) * unit);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pyt[t * NS + n] = (float)(cy - (32 * t + 16) * unit);
+            wf[n] = (float)w;
         }
-        for (int n = NP + tid; n < NP + 2 * WRSN_OBS_CH; n += 256) { wf[n] = 0.f; pc[n * 2 + 0] = 0.0; pc[n * 2 + 1] = 0.0; }   // the expansion runs one chunk ahead
+        for (int n = NP + tid; n < NS; n += 256) {
+            wf[n] = 0.f;
+            for (int w = 0; w < 3; ++w) pxb[w * NS + n] = 0.f;
+            for (int t = 0; t < 4; ++t) pyt[t * NS + n] = 0.f;
+        }
     }
     wrsn_v16f acc[4];
 #pragma unroll
@@ -2479,21 +2507,19 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
         for (int k = 0; k < WRSN_OBS_CH; ++k) {
             const int n = c * WRSN_OBS_CH + k;
             if (wf[n] != 0.f) {                                // a zero weight (dead node, padding) reaches nothing
-                const float x = (float)pc[n * 2], y = (float)pc[n * 2 + 1];
+                const float x = pxb[n] + (float)(16 * unit), y = pyt[n] + (float)(16 * unit);
                 xlo = fminf(xlo, x); xhi = fmaxf(xhi, x); ylo = fminf(ylo, y); yhi = fmaxf(yhi, y);
             }
         }
         bbox[4 * c + 0] = xlo; bbox[4 * c + 1] = xhi; bbox[4 * c + 2] = ylo; bbox[4 * c + 3] = yhi;
     }
-    __syncthreads();
-    auto maps234 = [&]() {
-    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.
-    // Term rows gx[t][G] (already scaled) and gy[t][G] go to LDS; every thread then produces elements tid, tid+256, ...
-    // Even blocks produce them before map 1, odd blocks after it: the blocks of a CU start together, and this way the
-    // store-bound phase of one half (3/4 of the observation) overlaps the matrix-core phase of the other half.  The term
-    // rows live in the (then unused) wave buffers: before the map-1 loop starts and after it ends.
-    float* tx = A; float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
-    const WrsnAgent* ag = dy->ag;
+    // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.  Their term rows
+    // gx[t][G] (already scaled) and gy[t][G] go to LDS rows of their own; wave 3 (the "store wave", below) turns them into the
+    // three maps while waves 0..2 are busy with the matrix cores.
+    float* tx = A + 3 * (WRSN_OBS_CH * (32 + WRSN_OBS_LD)); float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
+    int* row_ctr = tmap + WRSN_MAX_MC;                     // next pair of rows of maps 2..4 to be written (claimed with an LDS atomic)
+    {
+    const WrsnAgent* ag = sag;
     for (int o = 0; o < M; ++o) {
         int mp; double cxo, cyo, hx, hy, val;
         if (o == aid) {
@@ -2516,34 +2542,10 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
         }
         if (tid == 0) tmap[o] = mp;
     }
-    __syncthreads();
-#ifndef WRSN_OBS_NO_MAPS234
-    {   // thread = column j (tid & 127), rows tid >> 7, +2, ...: the y factors of the column sit in registers, already
-        // routed to their map, and a row costs one broadcast LDS read and three FMAs per charger
-        const int j = tid & (WRSN_OBS_LD - 1);
-        float g1[WRSN_MAX_MC], g2[WRSN_MAX_MC], g3[WRSN_MAX_MC];
-#pragma unroll
-        for (int o = 0; o < WRSN_MAX_MC; ++o) {
-            const float g = (o < M) ? ty[o * WRSN_OBS_LD + j] : 0.f; const int mp = (o < M) ? tmap[o] : 0;
-            g1[o] = (mp == 1) ? g : 0.f; g2[o] = (mp == 2) ? g : 0.f; g3[o] = (mp == 3) ? g : 0.f;
-        }
-        if (j < G) {
-            float* o2 = out + (size_t)G * G + j; float* o3 = o2 + (size_t)G * G; float* o4 = o3 + (size_t)G * G;
-            for (int i = tid >> 7; i < G; i += 2) {
-                float v1 = 0.f, v2 = 0.f, v3 = 0.f;
-#pragma unroll
-                for (int o = 0; o < WRSN_MAX_MC; ++o) {
-                    if (o < M) { const float t = tx[o * WRSN_OBS_LD + i]; v1 = fmaf(t, g1[o], v1); v2 = fmaf(t, g2[o], v2); v3 = fmaf(t, g3[o], v3); }
-                }
-                o2[(size_t)i * G] = v1; o3[(size_t)i * G] = v2; o4[(size_t)i * G] = v3;
-            }
-        }
+    if (tid == 0) *row_ctr = 0;
     }
-#endif
-    };
+    __syncthreads();
     WRSN_OBS_STAMP(1)
-    const bool maps_first = (blockIdx.x & 1) == 0;
-    if (maps_first) { maps234(); __syncthreads(); }
     WRSN_OBS_STAMP(2)
     // Map 1: every wave works on its own 32-row band with LDS buffers of its own and walks only the chunks (eight nodes
     // each, Morton order: neighbours in the plane) with a weighted node that reaches a row of the band -- a Gaussian
@@ -2554,59 +2556,160 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     float* Aw = A + wave * (WRSN_OBS_CH * (32 + WRSN_OBS_LD));   // [CH][32]   weight * g(x_row - x_n) for the band's rows
     float* Bw = Aw + WRSN_OBS_CH * 32;                           // [CH][128]  g(y - y_n)
     const float kx = inv2hx * 1.44269504f, ky = inv2hy * 1.44269504f;       // exp(t) = 2^(t log2 e)
-    const double cenx = unit / 2 + (row0 + l31) * unit;                    // this lane's x column (A part: node (l >> 5) + 2 m)
-    const double ceny0 = unit / 2 + l * unit, ceny1 = unit / 2 + (l + 64) * unit;   // its two y columns (B part: node m >> 1)
-    const float rx = 6.5f * (float)hX;
+    const float off = (float)((l31 - 15.5) * unit);        // this lane's row (A) / column (B) relative to the band / tile centre
+    const float rx = 6.5f * (float)hX, ry = 6.5f * (float)hY;
     const float band_lo = (float)((row0 + 0.5) * unit), band_hi = (float)((row0 + 31.5) * unit);
     const int nchunk = (N + WRSN_OBS_CH - 1) / WRSN_OBS_CH;
-    if (band) {
+    const bool mfma_wave = wave < 3 && band;               // rows 0..95 on the matrix cores; wave 3 is the store wave
+    if (mfma_wave) {
+        const float* pxw = pxb + wave * NS;
         for (int c = 0; c < nchunk; ++c) {
             const bool need = __builtin_amdgcn_readfirstlane((int)(bbox[4 * c + 0] - rx <= band_hi && bbox[4 * c + 1] + rx >= band_lo)) != 0;
             if (!need) continue;
-            const double* pn = pc + (size_t)c * WRSN_OBS_CH * 2; const float* wn = wf + c * WRSN_OBS_CH;
-#ifndef WRSN_OBS_NO_FILL
+            // the same cut-off along y: which of the four 32-column tiles the chunk's nodes reach at all (wave-uniform)
+            const float cy_lo = bbox[4 * c + 2] - ry, cy_hi = bbox[4 * c + 3] + ry;
+            int tmask = 0;
 #pragma unroll
-            for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {          // A: node (l >> 5) + 2 m, column l & 31
+            for (int t = 0; t < 4; ++t) tmask |= (int)(cy_lo <= (float)((32 * t + 31.5) * unit) && cy_hi >= (float)((32 * t + 0.5) * unit)) << t;
+            tmask = __builtin_amdgcn_readfirstlane(tmask);
+            const float* wn = wf + c * WRSN_OBS_CH;
+#ifndef WRSN_OBS_NO_FILL
+            // A [8 nodes][32 rows] and, per tile in reach, B [8 nodes][32 columns]: a lane expands node (l >> 5) + 2 m at row / column l & 31
+#pragma unroll
+            for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {
                 const int n = half + 2 * m;
-                const float df = (float)(cenx - pn[n * 2]);         // difference in float64, then float32
+                const float df = off - pxw[c * WRSN_OBS_CH + n];
                 Aw[n * 32 + l31] = __builtin_amdgcn_exp2f(df * df * kx) * wn[n];
             }
 #pragma unroll
-            for (int n = 0; n < WRSN_OBS_CH; ++n) {              // B: node n, columns l and l + 64
-                const double py = pn[n * 2 + 1];
-                const float d0 = (float)(ceny0 - py), d1 = (float)(ceny1 - py);
-                Bw[n * WRSN_OBS_LD + l] = __builtin_amdgcn_exp2f(d0 * d0 * ky);
-                Bw[n * WRSN_OBS_LD + l + 64] = __builtin_amdgcn_exp2f(d1 * d1 * ky);
+            for (int t = 0; t < 4; ++t) {
+                if ((tmask >> t) & 1) {
+                    const float* pyw = pyt + t * NS + c * WRSN_OBS_CH;
+#pragma unroll
+                    for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {
+                        const int n = half + 2 * m;
+                        const float df = off - pyw[n];
+                        Bw[n * WRSN_OBS_LD + 32 * t + l31] = __builtin_amdgcn_exp2f(df * df * ky);
+                    }
+                }
             }
 #endif
             __builtin_amdgcn_wave_barrier();
 #ifndef WRSN_OBS_NO_MFMA
+            // D[m][n] = sum_k Ay[m][k] Bx[k][n] with m = map column inside tile t, n = band row: the accumulator registers of a
+            // lane then run along the map's COLUMNS (row = lane & 31), which lets the store below write 16 bytes at a time
 #pragma unroll
             for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
-                // A operand: lane -> A[i = l & 31][k = l >> 5];  B operand: lane -> B[k = l >> 5][j = l & 31]
-                const float a = Aw[(k2 + half) * 32 + l31];
+                // first operand: lane -> [m = l & 31][k = l >> 5];  second operand: lane -> [k = l >> 5][n = l & 31]
+                const float bx = Aw[(k2 + half) * 32 + l31];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bw[(k2 + half) * WRSN_OBS_LD + 32 * t + l31], acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t)
+                    if ((tmask >> t) & 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[(k2 + half) * WRSN_OBS_LD + 32 * t + l31], bx, acc[t], 0, 0, 0);
             }
 #endif
             __builtin_amdgcn_wave_barrier();                   // the next chunk overwrites the buffers
         }
     }
     WRSN_OBS_STAMP(3)
-    // map 1 store.  C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if (band) {
+    // map 1 store.  C/D layout: col (n) = lane & 31 = band row, row (m) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) = column in the
+    // tile: registers 4 g .. 4 g + 3 of a lane are four consecutive map columns of one map row -> one 16-byte store
+    if (mfma_wave) {
+        const int i = row0 + l31;
+        if (i < G) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int j = 32 * t + l31;
+            for (int t = 0; t < 4; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (i < G && j < G) out[(size_t)i * G + j] = acc[t][r];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int j = 32 * t + 8 * g4 + 4 * half;
+                    if (j + 3 < G) {
+                        float4 v; v.x = acc[t][4 * g4]; v.y = acc[t][4 * g4 + 1]; v.z = acc[t][4 * g4 + 2]; v.w = acc[t][4 * g4 + 3];
+                        *(float4*)(out + (size_t)i * G + j) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (j + q < G) out[(size_t)i * G + j + q] = acc[t][4 * g4 + q];
+                    }
+                }
             }
         }
     }
     WRSN_OBS_STAMP(4)
-    if (!maps_first) { __syncthreads(); maps234(); }
+    if (wave == 3) {
+        // ---- the store wave, part 1.  Rows 96 .. G-1 of map 1 (4 rows at G = 100: a fourth matrix-core band would be 7/8 idle) as
+        // rank-1 updates on the VALU: a lane owns columns l and l + 64, four rows at a time in registers; the same Morton order,
+        // chunk cut-off (6.5 bandwidths) and float32 fma chain as the matrix-core bands.
+        for (int rb = 96; rb < G; rb += 4) {
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+            const float lo = (float)((rb + 0.5) * unit), hi = (float)((rb + 3.5) * unit);
+            float offr[4];                                     // rows rb .. rb + 3 relative to the centre of band 2 (row 80)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) offr[q] = (float)((rb + q - 80 + 0.5) * unit);
+            const float* px2 = pxb + 2 * NS; const float* py0 = pyt + half * NS; const float* py1 = pyt + (2 + half) * NS;   // columns l, l + 64
+            for (int c = 0; c < nchunk; ++c) {
+                if (!(bbox[4 * c + 0] - rx <= hi && bbox[4 * c + 1] + rx >= lo)) continue;      // wave-uniform (LDS broadcast values)
+                float wn[WRSN_OBS_CH], xs[WRSN_OBS_CH], y0s[WRSN_OBS_CH], y1s[WRSN_OBS_CH];
+#pragma unroll
+                for (int k = 0; k < WRSN_OBS_CH; ++k) { const int n = c * WRSN_OBS_CH + k; wn[k] = wf[n]; xs[k] = px2[n]; y0s[k] = py0[n]; y1s[k] = py1[n]; }
+#pragma unroll
+                for (int k = 0; k < WRSN_OBS_CH; ++k) {
+                    const float d0 = off - y0s[k], d1 = off - y1s[k];
+                    const float g0 = __builtin_amdgcn_exp2f(d0 * d0 * ky), g1 = __builtin_amdgcn_exp2f(d1 * d1 * ky);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float df = offr[q] - xs[k];
+                        const float gx = __builtin_amdgcn_exp2f(df * df * kx) * wn[k];       // weight 0 (dead node / padding): adds +0
+                        a0[q] = fmaf(g0, gx, a0[q]); a1[q] = fmaf(g1, gx, a1[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (rb + q < G) { if (l < G) out[(size_t)(rb + q) * G + l] = a0[q]; if (l + 64 < G) out[(size_t)(rb + q) * G + l + 64] = a1[q]; }
+            }
+        }
+    }
+    {   // ---- maps 2..4, shared by all four waves: the store wave starts at once, the matrix-core waves join when their band is
+        // written.  A wave claims the next pair of map rows from an LDS counter (lanes 0..31 take row 2 p, lanes 32..63 row 2 p + 1);
+        // a lane owns FOUR consecutive columns (their y factors sit in registers) and writes 16 bytes per map and row: one
+        // broadcast LDS read and four FMAs per charger.
+        const int nq = (G + 3) >> 2, jq = l31, j = 4 * jq;
+        float gq[WRSN_MAX_MC][4]; int mps[WRSN_MAX_MC];
+#pragma unroll
+        for (int o = 0; o < WRSN_MAX_MC; ++o) {
+            mps[o] = (o < M) ? __builtin_amdgcn_readfirstlane(tmap[o]) : 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gq[o][c] = (o < M && jq < nq && j + c < G) ? ty[o * WRSN_OBS_LD + j + c] : 0.f;
+        }
+        float* o2 = out + (size_t)G * G + j; float* o3 = o2 + (size_t)G * G; float* o4 = o3 + (size_t)G * G;
+        const bool vec = ((G & 3) == 0);
+        const int npair = (G + 1) >> 1;
+        for (;;) {
+            int rp = 0;
+            if (l == 0) rp = atomicAdd(row_ctr, 1);
+            rp = wrsn_wave_first(rp);
+            if (rp >= npair) break;
+            const int i = 2 * rp + half;
+            if (i < G && jq < nq) {
+                float v1[4] = {0.f, 0.f, 0.f, 0.f}, v2[4] = {0.f, 0.f, 0.f, 0.f}, v3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < WRSN_MAX_MC; ++o) {
+                    if (o < M) {
+                        const float t = tx[o * WRSN_OBS_LD + i];
+                        if (mps[o] == 1) { for (int c = 0; c < 4; ++c) v1[c] = fmaf(t, gq[o][c], v1[c]); }
+                        else if (mps[o] == 2) { for (int c = 0; c < 4; ++c) v2[c] = fmaf(t, gq[o][c], v2[c]); }
+                        else { for (int c = 0; c < 4; ++c) v3[c] = fmaf(t, gq[o][c], v3[c]); }
+                    }
+                }
+                if (vec) {
+                    float4 a; a.x = v1[0]; a.y = v1[1]; a.z = v1[2]; a.w = v1[3]; *(float4*)(o2 + (size_t)i * G) = a;
+                    float4 b; b.x = v2[0]; b.y = v2[1]; b.z = v2[2]; b.w = v2[3]; *(float4*)(o3 + (size_t)i * G) = b;
+                    float4 d4; d4.x = v3[0]; d4.y = v3[1]; d4.z = v3[2]; d4.w = v3[3]; *(float4*)(o4 + (size_t)i * G) = d4;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) if (j + c < G) { o2[(size_t)i * G + c] = v1[c]; o3[(size_t)i * G + c] = v2[c]; o4[(size_t)i * G + c] = v3[c]; }
+                }
+            }
+        }
+    }
 #ifdef WRSN_OBS_PROF
     ot_[5] = clock64();
     if (tid == 0) for (int q = 0; q < 5; ++q) d.counters[(size_t)env * 24 + q] = ot_[q + 1] - ot_[q];
@@ -2614,4 +2717,4 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
 #endif
 }
 
-static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * (2 * 8 + 4) + 16 * (NP / WRSN_OBS_CH + 2) + 4 * WRSN_OBS_CH * (32 + WRSN_OBS_LD) * 4 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * 8 * 4 + 16 * (NP / WRSN_OBS_CH + 2) + 3 * WRSN_OBS_CH * (32 + WRSN_OBS_LD) * 4 + 2 * WRSN_MAX_MC * WRSN_OBS_LD * 4 + 64; }

@@ -449,7 +449,7 @@ class BatchedIPPO(PPOLearner):
                 var_y = np.var(y_true)
                 ev = float("nan") if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y
                 row = dict(iteration=lg["i_so_far"], timesteps=lg["t_so_far"], agent=id, policy_loss=st[0], value_loss=st[1], entropy=st[2],
-                           approx_kl=st[3], clipfrac=st[4], explained_variance=ev, mean_reward=lg["rewards"][-1],
+                           approx_kl=st[3], clipfrac=st[4], explained_variance=float(ev), mean_reward=lg["rewards"][-1],
                            sps=i_so_far / (time.time() - start))
                 rows.append(row)
                 if self.log:

@@ -9,6 +9,7 @@ alignas(16) double smem[160 * 1024 / 8];
 unsigned char emu_slots[2][256][16];
 int emu_parity = 0;
 int emu_block_order = 0;
+int emu_wave_first_slot[4];
 extern "C" void emu_set_block_order(int o) { emu_block_order = o; }
 float emu_mfma_a[4][64], emu_mfma_b[4][64];
 

@@ -102,6 +102,17 @@ inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int /*bank_m
 inline int emu_readlane(int v, int src) { return emu_exchange(v, src); }
 #define __builtin_amdgcn_readlane emu_readlane
 #define __builtin_amdgcn_readfirstlane(x) (x)
+// a real lane-0 broadcast inside ONE wavefront (waves of a block may call it different numbers of times)
+#define WRSN_WAVE_FIRST_DEFINED
+extern int emu_wave_first_slot[4];
+inline int wrsn_wave_first(int v) {
+    const int w = (int)threadIdx.x >> 6;
+    if (((int)threadIdx.x & 63) == 0) emu_wave_first_slot[w] = v;
+    emu_wave_barrier();
+    const int r = emu_wave_first_slot[w];
+    emu_wave_barrier();
+    return r;
+}
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()   /* lanes of one wave are fibers here: order their LDS traffic */   /* only used on wave-uniform values */
 // the LDS gathers of wrsn_sim.h are inline assembly (eight ds_read back to back): plain loads here
 #define WRSN_LDS_GATHER_DEFINED
