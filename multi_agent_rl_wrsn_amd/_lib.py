@@ -113,6 +113,13 @@ def load():
     """Load the in-tree HIP library.  Fails loudly when it has not been built."""
     global _lib
     if _lib is None:
+        # torch ships its own copy of the HIP runtime (same SONAME as /opt/rocm's).  Whichever copy is mapped first serves every
+        # later dlopen; if this library came first, torch would bring a SECOND runtime into the process and the one bound here
+        # would find no device ("no ROCm-capable device is detected").  Import torch first so that there is exactly one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         alt = os.environ.get("WRSN_HIP_LIB")                   # diagnostic: another BUILD OF THE SAME HIP library (A/B timing runs)
         if alt:
             _lib = bind(C.CDLL(alt))

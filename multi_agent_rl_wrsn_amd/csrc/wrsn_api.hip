@@ -174,7 +174,11 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         cfg->map_size > 128 || cfg->n_node > 1024 || !(cfg->warm_up_time > 0.0))
         return fail(WRSN_ERR_ARG, "wrsn_cfg out of range (n_mc 1..8, n_node 1..1024, map_size 4..128, warm_up_time > 0)");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(WRSN_ERR_NO_DEVICE, "no HIP device: libwrsn_hip has no CPU fallback");
+    {
+        const hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            return fail(WRSN_ERR_NO_DEVICE, std::string("no HIP device: libwrsn_hip has no CPU fallback (hipGetDeviceCount: ") + hipGetErrorString(e) + ")");
+    }
     if (cfg->device < 0 || cfg->device >= ndev) return fail(WRSN_ERR_ARG, "device ordinal out of range");
     DeviceGuard guard_(cfg->device);
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
