@@ -22,7 +22,7 @@ def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
     rng = np.random.RandomState(seed0)
     pool = ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 8))
     n_cmp = 0; n_term = 0; n_noise = 0; worst_rew = 0.0; worst_obs = 0.0; t0 = time.time()
-    busy = np.zeros(B, dtype=bool); pending = [None] * B; resets = np.zeros(B, dtype=int)
+    busy = np.zeros(B, dtype=bool); pending = [None] * B; resets = np.zeros(B, dtype=int); topo_cache = {}
     for step in range(K):
         act = rng.rand(B, 3)
         ids = np.full(B, -1, dtype=np.int64)
@@ -72,6 +72,17 @@ def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
                     scale = max(np.abs(gcs).max(), 1e-30)
                     noisy = alive_ & (((np.abs(gcs) < 1e-9 * scale) & (gcs != 0)) | ((np.abs(ocs) < 1e-9 * scale) & (ocs != 0)))
                     if noisy.any():
+                        # the escape hatch is pinned: node state (status, energies) matched above, and the GPU's fitness / reward must be
+                        # exactly what the reference's algorithm (tests/fitness_ref.py: WRSN.py:188-227) gives on the GPU's OWN node state
+                        import fitness_ref
+                        if e not in topo_cache:
+                            topo_cache[e] = fitness_ref.Topology(scs[e].node_xy, scs[e].target_xy, scs[e].bs_xy, float(scs[e].node_spec["com_range"]), float(scs[e].node_spec["sen_range"]))
+                        gm = env.mcs(); gi = env.env_info(); a_ = x["agent_id"]
+                        fit = fitness_ref.network_fitness(topo_cache[e], nd["energy"][e][:scs[e].n_node], nd["cs"][e][:scs[e].n_node], nd["status"][e][:scs[e].n_node], float(scs[e].node_spec["threshold"]))
+                        assert close(gi["min_fitness"][e], fit.min(), rtol=1e-9), ("fitness on own state", step, e, gi["min_fitness"][e], fit.min())
+                        want = fitness_ref.reward(fit.min(), gm["prev_minfit"][e][a_], gm["excl"][e][a_], gi["avg_nodes_agent"][e], gi["charging_time_max"][e], gi["moving_time_max"][e])
+                        sc_ = (0.8 * abs(fit.min() - gm["prev_minfit"][e][a_]) + 0.2 * abs(gm["excl"][e][a_]) / gi["avg_nodes_agent"][e]) / (gi["charging_time_max"][e] + gi["moving_time_max"][e])
+                        assert abs(float(rew[e]) - want) <= 1e-5 * max(abs(want), sc_) + 1e-12, ("reward on own state", step, e, float(rew[e]), want)
                         n_noise += 1
                         continue
                     gm = env.mcs(); om = ors[e].mcs(); gi = env.env_info(); oi = ors[e].env_info()
@@ -87,6 +98,7 @@ def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
             print("step %d: %d requests compared (%d noise-dependent), %d episodes finished, worst reward rel err %.2e, worst obs err %.2e, %.0f s" % (step + 1, n_cmp, n_noise, n_term, worst_rew, worst_obs, time.time() - t0), flush=True)
     print("parity sweep ok: %d requests, %d finished episodes; %d requests with a reward that depends on the sign of a rounding-noise energyCS (not comparable)" % (n_cmp, n_term, n_noise))
     env.close(); pool.shutdown()
+    assert n_noise <= max(2, n_cmp // 200), "more than 0.5 %% of the requests hang on a rounding-residue energyCS: %d of %d" % (n_noise, n_cmp)
     return n_cmp, n_term, n_noise
 
 

@@ -366,3 +366,25 @@ def test_emulated_untouched_and_unmasked_rows_keep_their_request():
     ev.step(ids, rng.rand(3, 3))
     for e in (0, 2):
         assert ev.agent_id[e] == keep1[0][e] and ev.reward[e] == keep1[1][e] and ev.now[e] == keep1[2][e] and np.array_equal(ev.obs[e], keep1[3][e])
+
+
+@pytest.mark.parametrize("G", [12, 96, 128])
+def test_emulated_observation_at_other_map_sizes(G):
+    """get_state (WRSN.py:130-186) at map sizes that exercise the corners of the observation kernel's tiling: fewer rows than one
+    matrix-core band (12), exactly three bands and no VALU rows (96), a full fourth band on the store wave (128)."""
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    from wrsn_oracle import OracleWRSN
+    sc = synth_scenario(33, 90, 70)
+    M = 3
+    ev = _emu([sc], DEFAULT_MC_SPEC, M, map_size=G)
+    o = OracleWRSN(sc.node_xy, sc.target_xy, sc.bs_xy, sc.node_spec, DEFAULT_MC_SPEC, sc.max_time, M, map_size=G)
+    ev.reset(); r = o.reset()
+    assert np.max(np.abs(ev.obs[0] - r["state"])) <= 1e-5 * max(1.0, np.abs(r["state"]).max())
+    rng = np.random.RandomState(4)
+    for k in range(5):
+        a = rng.rand(3)
+        ev.step([int(ev.agent_id[0])], a[None]); r = o.step(r["agent_id"], a)
+        if r["terminal"] or r["agent_id"] is None:
+            break
+        assert int(ev.agent_id[0]) == r["agent_id"]
+        assert np.max(np.abs(ev.obs[0] - r["state"])) <= 1e-5 * max(1.0, np.abs(r["state"]).max()), k

@@ -202,6 +202,62 @@ def test_full_size_properties_4096_envs_200_nodes():
     env.close()
 
 
+def test_full_size_properties_4096_envs_1000_nodes_8_chargers():
+    """BASELINE configs[4] at full size (4096 environments x 1000 nodes x 8 chargers, sixteen register slots per lane):
+    replica invariance and determinism of a whole batch, spot checks against the oracle, monotone drain without charging."""
+    torch = _torch()
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, VecWRSN, synth_scenario
+    from wrsn_oracle import OracleWRSN
+    B, U, M, K = 4096, 16, 8, 10
+    uniq = [synth_scenario(7000 + u, 1000, 1000) for u in range(U)]
+    scs = [uniq[e % U] for e in range(B)]
+    env = VecWRSN(scs, None, M, auto_reset=False, render=False)
+    g = torch.Generator().manual_seed(5)
+    acts_u = torch.rand((K, U, 3), generator=g, dtype=torch.float64)
+
+    def rollout():
+        r = env.reset()
+        trace = []
+        for k in range(K):
+            r = env.step(r["agent_id"].clone(), acts_u[k].repeat(B // U, 1))
+            trace.append((r["agent_id"].clone(), r["now"].clone(), r["reward"].clone(), r["terminal"].clone()))
+        env.synchronize()
+        return trace, env.nodes()["energy"].copy()
+    t1, e1 = rollout()
+    t2, e2 = rollout()
+    assert np.array_equal(e1, e2)
+    for a, b in zip(t1, t2):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    for a in t1:
+        for x in a:
+            xs = x.reshape(B // U, U)
+            assert torch.equal(xs, xs[0:1].expand_as(xs))
+    for e in (0, 5, 4095):
+        s = scs[e]
+        o = OracleWRSN(s.node_xy, s.target_xy, s.bs_xy, s.node_spec, DEFAULT_MC_SPEC, s.max_time, M)
+        x = o.reset(with_state=False)
+        for k in range(K):
+            if x["terminal"]:
+                break
+            x = o.step(x["agent_id"], acts_u[k][e % U].numpy(), with_state=False)
+            assert int(t1[k][0][e]) == (-1 if x["agent_id"] is None else x["agent_id"]), (e, k)
+            assert close(float(t1[k][1][e]), x["now"], rtol=1e-9), (e, k)
+            if x["agent_id"] is not None and not x["terminal"]:
+                assert close(float(t1[k][2][e]), x["reward"], atol=1e-9), (e, k)
+        if not x["terminal"]:
+            assert close(e1[e, :1000], o.nodes()["energy"])
+    r = env.reset()
+    prev = env.nodes()["energy"].copy()
+    for k in range(3):
+        a = torch.rand((B, 3), generator=g, dtype=torch.float64); a[:, 2] = 0.0
+        r = env.step(r["agent_id"].clone(), a)
+        cur = env.nodes()["energy"]
+        assert np.all(cur <= prev + 1e-9)
+        prev = cur.copy()
+    env.close()
+
+
 def test_step_budget_gives_the_same_requests_as_blocking_steps():
     """wrsn_set_step_budget only changes the launch a request is reported in: per environment the sequence of requests
     (agent, simulated time, reward, terminal, observation) of a budgeted run equals the blocking run (float64 values to
