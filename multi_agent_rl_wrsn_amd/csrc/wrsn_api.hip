@@ -63,6 +63,8 @@ struct wrsn_handle {
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
+    int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
+    int bp2;                   // B rounded up to a power of two when the launch order is sorted on the device (B <= 8192), else 0
     std::vector<void*> allocs;
     WrsnDev* d_dev;            // device copy of `dev`: the environment kernels read it through the constant cache
 };
@@ -104,9 +106,14 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     const int lds = h->lds_env + h->lds_pad;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
-    dim3 grid(budget > 0 ? 2 * nenv : nenv), block(64);
+    dim3 grid(nenv), block(64);
     long long epoch = 0;
-    if (budget > 0) epoch = ++h->epoch;                        // the kernel itself empties the list the launch after it fills
+    if (budget > 0) epoch = ++h->epoch;                        // parity selects the hand-off list of the two-launch variant
+    if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
+        // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
+        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
+        hipLaunchKernelGGL(wrsn_sort_kernel, dim3(1), dim3(WRSN_SORT_THREADS), (size_t)h->bp2 * sizeof(uint32_t), h->stream, h->dev, h->bp2);
+    }
     // A budgeted step is two launches: the lean variant of the step kernel over all environments (no code for the level BFS,
     // the routing rebuild and the packet-exact second: no scratch memory), then the full variant over the few environments
     // the lean one stopped in front of such a service (hand-off list; the other blocks leave at once).
@@ -114,11 +121,11 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else if (budget > 0 && h->split) {                                                                                 \
         hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, h->slots, mask, out, 1);                                         \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 1);                                         \
         hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv), block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, h->slots, mask, out, 2);                                         \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 2);                                         \
     } else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                            auto_reset, budget, epoch, h->slots, mask, out, 0)
+                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 0)
     switch (h->npl) {
     case 1: WRSN_LAUNCH(1); break;
     case 2: WRSN_LAUNCH(2); break;
@@ -185,6 +192,12 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     wrsn_handle* h = new wrsn_handle();
     h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1;
     { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
+    {   // budget taper over the launch order (units of slots / 8 blocks): start 8 = after the first `slots` blocks, length 16 = down to
+        // zero over two times `slots` blocks (the floor of a quarter applies first); WRSN_TAPER="start,len" overrides (diagnostic)
+        int ts = 8, tl = 16; const char* e = std::getenv("WRSN_TAPER");
+        if (e) { int a = 0, b = 0; if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && a < 256 && b > 0 && b < 256) { ts = a; tl = b; } }
+        h->taper = (ts << 16) | (tl << 24);
+    }
     { const char* e = std::getenv("WRSN_LDS_PAD"); h->lds_pad = e ? std::atoi(e) : 0; if (h->lds_pad < 0 || h->lds_pad > 100000) h->lds_pad = 0; }
     { hipDeviceProp_t pr; h->slots = (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount * 8 : 2048; }
     h->npl = npl_for(cfg->n_node);
@@ -227,8 +240,9 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = alloc_node_arrays(h, &d.live))) break;
         if ((rc = alloc_node_arrays(h, &d.snap))) break;
         if ((rc = dalloc(h, &d.counters, B * 25))) break;
-        if ((rc = dalloc(h, &d.prio_list, 3 * B))) break;
-        if ((rc = dalloc(h, &d.prio_n, 3))) break;
+        { int p2 = 1; while (p2 < d.B) p2 <<= 1; h->bp2 = (d.B <= 8192 && !std::getenv("WRSN_NO_ORDER")) ? p2 : 0; }
+        if ((rc = dalloc(h, &d.order_key, (size_t)(h->bp2 > 0 ? h->bp2 : 1)))) break;
+        if ((rc = dalloc(h, &d.order, (size_t)(h->bp2 > d.B ? h->bp2 : d.B)))) break;
         if ((rc = dalloc(h, &d.render_agent, B))) break;
         if ((rc = dalloc(h, &d.row_state, B))) break;
         if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
@@ -236,6 +250,10 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
     } while (0);
     if (rc) { wrsn_destroy(h); return rc; }
+    {   // identity launch order: what a handle too large for the device-side sort (or WRSN_NO_ORDER) keeps
+        std::vector<int32_t> ident(B); for (size_t e = 0; e < B; ++e) ident[e] = (int32_t)e;
+        if (hipMemcpy(d.order, ident.data(), B * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
+    }
     if (hipMemcpy(h->d_dev, &h->dev, sizeof(WrsnDev), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
     *out = h;
     return WRSN_OK;
@@ -336,9 +354,7 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     WRSN_ON_DEVICE(h);
     if ((work_units > 0) != (h->step_budget > 0)) {            // (re)entering budgeted mode: no environment is listed yet
         HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemset(h->dev.prio_n, 0, 3 * sizeof(int32_t)));
         HIPCHK(hipMemset(h->dev.heavy_n, 0, 2 * sizeof(int32_t)));
-        h->epoch += 4;                                         // stamps left by earlier budgeted launches name no future launch
     }
     h->step_budget = work_units;
     return WRSN_OK;

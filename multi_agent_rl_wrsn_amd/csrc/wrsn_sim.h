@@ -1561,6 +1561,12 @@ struct Sim {
         SAG()[a].type_charging = 0;
         if (used > SAG()[a].energy - EC()->mc_threshold - EC()->mc_capacity / 200.0) { STH()[ti].stage = 0; STH()[ti].m_dest[0] = EC()->bs[0]; STH()[ti].m_dest[1] = EC()->bs[1]; }
         else { STH()[ti].stage = 2; STH()[ti].m_dest[0] = dx; STH()[ti].m_dest[1] = dy; }
+        if (SAG()[a].cur_thread == ti) {                     // launch ordering: when the process WRSN.step waits for will finish
+            const double way = (STH()[ti].stage == 0)
+                ? dist2(EC()->bs[0], EC()->bs[1], SAG()[a].loc[0], SAG()[a].loc[1]) + dist2(dx, dy, EC()->bs[0], EC()->bs[1])
+                : dist2(dx, dy, SAG()[a].loc[0], SAG()[a].loc[1]);
+            SAG()[a].t_done = now + way / EC()->velocity + ct;
+        }
         th_sched(ti, PC_MOVE_INIT, WRSN_URGENT, now);
     }
 
@@ -1949,38 +1955,29 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
                                                        const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
-    // With a step budget the grid is 2 B blocks: the first B take the environments whose step is in flight (the long
-    // jobs of this launch, listed by the previous one) so that they start first; block B + r takes one of the others.
-    // Who owns an environment is decided from `listed_for` alone, a stamp written where a step suspends -- by the launch
-    // BEFORE this one for every environment this launch has listed -- or zeroed by a reset launch: a listed block owns
-    // its environment iff the stamp names this launch, block B + r owns its environment iff the stamp is older.  The
-    // only write during the launch is the owner's own (stamp = next launch, when its step suspends again), and that
-    // value still tells block B + r to keep out; nothing the owner stores while it finishes is looked at by the other.
-    int env = blockIdx.x; bool listed = false;
-    const int cur_l = (int)(epoch % 3), next_l = (int)((epoch + 1) % 3), hand_l = (int)(epoch & 1);
+    // Block b of a step launch takes environment order[b]: the environments sorted by the work their WRSN.step still needs,
+    // longest first (wrsn_estimate_kernel / wrsn_sort_kernel run in front of every step launch).  The duration of a WRSN.step is
+    // heavy-tailed and a launch ends with its last wave, so the long jobs have to start first; every environment appears exactly once
+    // in the order, so a launch owns an environment through one block only.
+    int env = blockIdx.x;
+    const int hand_l = (int)(epoch & 1);
     if (handoff == 2) {
         if ((int)blockIdx.x >= dp->heavy_n[hand_l]) return;
         env = dp->heavy_list[(size_t)hand_l * dp->B + blockIdx.x];
-    } else if (budget > 0 && !reset_call) {
-        if (blockIdx.x == 0 && lane == 0) {
-            dp->prio_n[(int)((epoch + 2) % 3)] = 0;          // the list the next launch fills (last read two launches ago)
-            dp->heavy_n[hand_l ^ 1] = 0;                     // the hand-off list of the next call (last read by the continuation launch before this call)
-        }
-        if ((int)blockIdx.x < dp->B) {
-            if ((int)blockIdx.x >= dp->prio_n[cur_l]) return;
-            env = dp->prio_list[(size_t)cur_l * dp->B + blockIdx.x]; listed = true;
-        } else {
+    } else if (!reset_call) {
+        env = dp->order[blockIdx.x];
+        if (budget > 0) {
+            if (blockIdx.x == 0 && lane == 0) dp->heavy_n[hand_l ^ 1] = 0;   // the hand-off list of the next call (last read by the continuation launch before this call)
             // blocks are dispatched in index order: a block far behind the first `slots` ones starts late, and what it is
-            // allowed to spend shrinks accordingly so that the launch does not wait for late long jobs.  The mapping
-            // block -> environment rotates with the launch number, so no environment is always last.
-            const int r = blockIdx.x - dp->B;
-            env = (int)(((long long)r + (epoch % dp->B) * 1031) % dp->B);
-            const int k = dp->prio_n[cur_l] + r - slots;
-#ifndef WRSN_BUDGET_SLOPE
-#define WRSN_BUDGET_SLOPE 2
+            // allowed to spend shrinks accordingly so that the launch does not wait for late long jobs
+            // (`slots` packs three launch parameters: wave slots of the device, block at which the taper starts, blocks over which the
+            //  budget falls to zero -- the floor of a quarter applies before that)
+            const int n_slots = slots & 0xFFFF, t_start = (slots >> 16) & 0xFF, t_len = (slots >> 24) & 0xFF;
+            const int k = (int)blockIdx.x - t_start * (n_slots / 8);
+#ifndef WRSN_BUDGET_FLOOR
 #define WRSN_BUDGET_FLOOR 4
 #endif
-            if (k > 0) { const int cut = (int)((long long)budget * k / (WRSN_BUDGET_SLOPE * slots)); budget = (budget - cut > budget / WRSN_BUDGET_FLOOR) ? budget - cut : budget / WRSN_BUDGET_FLOOR; }
+            if (k > 0) { const int cut = (int)((long long)budget * k / (t_len * (n_slots / 8))); budget = (budget - cut > budget / WRSN_BUDGET_FLOOR) ? budget - cut : budget / WRSN_BUDGET_FLOOR; }
         }
     }
     if (env < 0 || env >= dp->B) return;
@@ -1991,19 +1988,6 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     if (handoff == 2) resume = 1;                          // handed over by the lean launch of this call: the step is in flight
     else if (!reset_call) {
         aid = agent_id[env];
-        if (budget > 0) {
-            const long long stamp = dp->live.dyn[env].listed_for;
-            if (listed) {
-                if (stamp != epoch) return;                // reset since it was listed: block B + r owns it
-                if (aid == -2) {                           // left untouched: stays in flight, stays listed
-                    if (lane == 0) {
-                        const int pos = atomicAdd(&dp->prio_n[next_l], 1); dp->prio_list[(size_t)next_l * dp->B + pos] = env;
-                        dp->live.dyn[env].listed_for = epoch + 1; dp->render_agent[env] = -1; dp->row_state[env] = 0;
-                    }
-                    return;
-                }
-            } else if (stamp >= epoch) return;             // listed for this launch: the listed block owns it
-        }
         if (aid == -2) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
         resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
@@ -2100,10 +2084,6 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (!HEAVY && s.need_heavy) {                    // the continuation launch of this call goes on with it
                 const int pos = atomicAdd(&dp->heavy_n[hand_l], 1);
                 dp->heavy_list[(size_t)hand_l * dp->B + pos] = env;
-            } else if (budget > 0) {                         // first in line in the next launch
-                const int pos = atomicAdd(&dp->prio_n[next_l], 1);
-                dp->prio_list[(size_t)next_l * dp->B + pos] = env;
-                dy->listed_for = epoch + 1;
             }
         }
         if (lane == 0 && !susp) {
@@ -2137,7 +2117,6 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
       s.prof_[17] += k5_ - k4_;
 #endif
     }
-    if (lane == 0 && reset_call) dp->live.dyn[env].listed_for = 0;   // a reset launch takes the environment off the in-flight list
     if (lane == 0 && !do_reset) dp->live.dyn[env].tot_ticks += s.n_ticks - ticks0;
 #ifdef WRSN_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
@@ -2145,6 +2124,70 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     if (lane == 0) { dp->counters[(size_t)env * 24 + 22] = wt0_; dp->counters[(size_t)env * 24 + 23] = wall_clock64(); }
 #endif
 #endif
+}
+
+// ------------------------------------------------------------------ launch order of a step call: longest job first
+// wrsn_estimate_kernel: one thread per environment.  A WRSN.step runs until the first alive charger finishes its action
+// (WRSN.py:307-311), and when that happens is known in advance: a charger's action takes dist / velocity + charge time whatever its
+// energy (MobileCharger.py:81-97: a charger that runs dry waits the remaining time out), recorded as WrsnAgent.t_done when the action
+// started; for the charger that is handed an action in THIS call it follows from the action itself.  Work of the launch ~ simulated
+// seconds to go, plus a surcharge when a node may run dry on the way (packet-exact second + re-routing).
+// wrsn_sort_kernel: bitonic sort of the (work, environment) keys in LDS, one workgroup; ties by environment index: the order is a
+// pure function of the environment states, not of timing.
+__global__ void __launch_bounds__(256) wrsn_estimate_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ action,
+                                                            int auto_reset, int BP2) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= BP2) return;
+    if (e >= d.B) { d.order_key[e] = 0xFFFFFFFFu; return; }  // padding sorts to the end
+    const WrsnEnvDyn* dy = d.live.dyn + e; const WrsnEnvConst* ec = d.ec + e;
+    const int aid = agent_id[e];
+    double w = 0.0;
+    if (aid != -2 && !(auto_reset && dy->terminal_pending)) {
+        const double now = dy->now;
+        double t_first = 1.0e30;
+        for (int m = 0; m < d.M; ++m) {
+            const WrsnAgent* a = dy->ag + m;
+            if (a->status == 0) continue;
+            double t = a->t_done;
+            if (!dy->susp && m == aid) {                     // the action of this call: translate (WRSN.py:95-98) + move + charge
+                double ax = action[(size_t)e * 3], ay = action[(size_t)e * 3 + 1], az = action[(size_t)e * 3 + 2];
+                ax = ax < 0.0 ? 0.0 : (ax > 1.0 ? 1.0 : ax); ay = ay < 0.0 ? 0.0 : (ay > 1.0 ? 1.0 : ay); az = az < 0.0 ? 0.0 : (az > 1.0 ? 1.0 : az);
+                const double px = ax * (ec->frame[1] - ec->frame[0]) + ec->frame[0], py = ay * (ec->frame[3] - ec->frame[2]) + ec->frame[2];
+                t = now + dist2(px, py, a->loc[0], a->loc[1]) / ec->velocity + ec->charging_time_max * az;
+            }
+            t_first = t < t_first ? t : t_first;
+        }
+        w = t_first - now;
+        w = w > 0.0 ? (w < 1.0e4 ? w : 1.0e4) : 0.0;
+        if (dy->frozen) w = 0.0;                             // network declared dead: the rest of the step is a jump
+        else if ((double)dy->safe_ticks < w) w += 250.0;     // a node may run dry before the step ends
+        w += 8.0;                                            // load / events / fitness / store of a step that has anything to do
+    }
+    unsigned q = (unsigned)(w * 4.0); q = q > 0xFFFFu ? 0xFFFFu : q;
+    d.order_key[e] = ((0xFFFFu - q) << 13) | (unsigned)e;    // ascending sort = longest first, ties by environment index
+}
+
+#ifndef WRSN_SORT_THREADS
+#define WRSN_SORT_THREADS 1024                               // the CPU emulator of tests/emu runs at most 256 fibers per block and says so
+#endif
+__global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d, int BP2) {
+    extern __shared__ double smem[];
+    unsigned* k = (unsigned*)smem;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < BP2; i += WRSN_SORT_THREADS) k[i] = d.order_key[i];
+    __syncthreads();
+    for (int size = 2; size <= BP2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < BP2 / 2; i += WRSN_SORT_THREADS) {
+                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;     // pair (lo, lo + stride) of the bitonic network
+                const bool up = (lo & size) == 0;
+                const unsigned a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < BP2; i += WRSN_SORT_THREADS) d.order[i] = (int)(k[i] & 0x1FFFu);
 }
 
 // ------------------------------------------------------------------ topology kernel (one wave per environment)

@@ -29,6 +29,8 @@ struct WrsnAgent {
     double loc[2], energy, charging_rate, cur[3];   // location, energy, chargingRate, cur_phy_action
     double prev_minfit, excl, action[3];            // min(agents_prev_fitness), agents_exclusive_reward, agents_action
     double conn_loc[2];                             // charger location the cached connection rates were computed for
+    double t_done;                                  // env.now at which the action in progress ends (move + charge; exact unless the charger
+                                                    // runs dry): launch ordering only, nothing in the simulation reads it
     int32_t status, type_charging, n_conn, cur_thread;
     int32_t n_live, pad;                            // connections made by the running charge sub-step
 };
@@ -59,8 +61,7 @@ struct WrsnEnvDyn {
     int32_t net_phase, net_active, node_phase, alive;
     int32_t levels_dirty, cache_dirty, irreg, ring_len;
     int32_t ring_head, safe_ticks, frozen, terminal_pending;
-    int64_t listed_for;                      // step budget: launch whose in-flight list holds this environment (written where a step
-                                             // suspends, i.e. by the launch before; 0 after a reset)
+    int64_t reserved0;
     int32_t n_connected, error, log_pending, susp;   // susp: WRSN.step in flight (work budget of a launch used up)
     // the `|` conditions of the step in flight (WRSN.py:307-311); only meaningful while susp != 0
     double cond_time[WRSN_MAX_MC + 1]; int64_t cond_seq[WRSN_MAX_MC + 1];
@@ -101,9 +102,8 @@ struct WrsnDev {
     uint32_t *tcp;                    // [B][TP][4]  the first eight covering node ids of a target, packed alike
     WrsnNodeArrays live, snap;        // current state / post-warm-up snapshot
     int64_t *counters;                // [4]
-    int32_t *prio_list;               // [3][B] environments whose step is in flight (step budget): launch e reads list e % 3, fills
-                                      //        list (e + 1) % 3 and empties the count of list (e + 2) % 3 for the launch after it
-    int32_t *prio_n;                  // [3]    their counts
+    uint32_t *order_key;              // [BP2]  launch order of a step call, longest job first: (0xFFFF - estimated work) << 13 | environment,
+    int32_t *order;                   // [BP2]  sorted ascending; order[b] = environment of block b (BP2 = B rounded up to a power of two)
     int32_t *heavy_list;              // [2][B] hand-off of a budgeted step call: environments the lean launch stopped in front of a
     int32_t *heavy_n;                 // [2]    heavy service (level BFS, routing rebuild, packet-exact second); list (call & 1)
     int32_t *row_state;               // [B]    what the last environment launch did with the row: 0 left untouched, 1 WRSN.step completed

@@ -17,6 +17,7 @@
 #include <functional>
 
 #define __global__
+#define WRSN_SORT_THREADS 256                  /* at most 256 fibers per block here */
 #define __device__
 #define __host__
 #define __shared__
