@@ -105,26 +105,19 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
            "zero_steps": c1["zero_time_steps"] - c0["zero_time_steps"], "exact_ticks": c1["exact_ticks"],
            "table": RolloutStats.gather_table(env.rollout_table()), "t_set": t_set}   # the path's one exchange step (RCCL all-gather)
 
-    # ---- per-kernel timing pass (HIP events on the stream the kernels are launched on) ----------------------
-    stream = torch.cuda.current_stream(dev)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    t_env = t_obs = 0.0
+    # ---- per-kernel timing pass: HIP events recorded by the library itself on the stream the kernels are launched on
+    #      (wrsn_set_timing / wrsn_kernel_times): launch-order kernels, step kernel and observation kernel separately
+    t_env = t_obs = t_ord = 0.0
     ks = max(1, kernel_steps)
+    env._h.set_timing(True)
     steps_before = env.counters()["env_steps"]
     for _ in range(ks):
-        a = policy()
-        env._in_agent.copy_(r["agent_id"]); env._in_action.copy_(a)
-        ptrs = env._out_ptrs(); obs_ptr = ptrs.pop("obs")
-        ev[0].record(stream)
-        env._h.step(env._in_agent.data_ptr(), env._in_action.data_ptr(), True, obs=0, **ptrs)
-        ev[1].record(stream)
-        env._h.render(env.agent_id.data_ptr(), obs_ptr)
-        ev[2].record(stream)
-        torch.cuda.synchronize(dev)
-        t_env += ev[0].elapsed_time(ev[1]) * 1e-3
-        t_obs += ev[1].elapsed_time(ev[2]) * 1e-3
+        r = env.step(r["agent_id"], policy())
+        kt = env._h.kernel_times()
+        t_env += (kt["step_ms"] + kt["continuation_ms"]) * 1e-3; t_obs += kt["obs_ms"] * 1e-3; t_ord += kt["order_ms"] * 1e-3
+    env._h.set_timing(False)
     res["units"] = (env.counters()["env_steps"] - steps_before) / ks    # env-steps one launch completes (auto-resets excluded)
-    res["env_launch"] = t_env / ks; res["obs_launch"] = t_obs / ks
+    res["env_launch"] = t_env / ks; res["obs_launch"] = t_obs / ks; res["order_launch"] = t_ord / ks
     res["mean_episode_seconds"] = float(env.env_info()["n_ticks"].mean())
     env.close()
     return res
@@ -211,7 +204,7 @@ def main():
                     "sim_ticks_per_s": bres["sim_seconds_all"] / bel, "mean_ticks_per_env_step": bres["sim_seconds_all"] / max(1.0, bcnt),
                     "zero_time_step_share": bres["zero_steps_all"] / max(1.0, bcnt),
                     "kernels": {"wrsn_step_kernel_ms": 1e3 * bres["env_launch"], "wrsn_obs_kernel_ms": 1e3 * bres["obs_launch"],
-                                "env_steps_per_launch": bres["units"]},
+                                "launch_order_kernels_ms": 1e3 * bres["order_launch"], "env_steps_per_launch": bres["units"]},
                     "note": "step_budget 0: every launch runs each WRSN.step to its end and waits for the slowest environment"}
 
     phys_b, obs_b = algorithmic_bytes(N, T, M, G)
@@ -251,7 +244,8 @@ def main():
             "mean_episode_seconds_so_far": main_res["mean_episode_seconds"],
             "mean_return_table_rows": int(main_res["table"].shape[0]),
             "setup_s": {"generate": round(t_gen, 2), "topology+warmup": round(main_res["t_set"], 2)},
-            "kernels": {"wrsn_step_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch, "env_steps_per_launch": units},
+            "kernels": {"wrsn_step_kernel_ms": 1e3 * env_launch, "wrsn_obs_kernel_ms": 1e3 * obs_launch,
+                        "launch_order_kernels_ms": 1e3 * main_res["order_launch"], "env_steps_per_launch": units},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_unit * units, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
                          "whole_step_achieved_GBps": (phys_b + obs_b) * value / 1e9, "whole_step_frac": (phys_b + obs_b) * value / 1e9 / peak},

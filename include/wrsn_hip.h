@@ -204,6 +204,13 @@ int wrsn_render(wrsn_t *h, const int32_t *agent_id, float *obs);
 /* Copy internal state to HOST memory (parity tests, `net` / `agents` views).  Synchronises. */
 int wrsn_peek(wrsn_t *h, int32_t what, void *dst);
 
+/* Per-kernel timing of the step path with HIP events recorded on the handle's stream (the stream the kernels are launched on).
+ * wrsn_set_timing(h, 1) makes every following wrsn_step record four events; wrsn_kernel_times waits for the last call and
+ * returns, in milliseconds: ms[0] launch-order kernels (work estimate + sort), ms[1] step kernel, ms[2] continuation launch of the
+ * two-launch variant (0 otherwise), ms[3] observation kernel (0 when no observation was requested).  Measurement only. */
+int wrsn_set_timing(wrsn_t *h, int32_t on);
+int wrsn_kernel_times(wrsn_t *h, float *ms);
+
 /* Wait for the handle's stream. */
 int wrsn_sync(wrsn_t *h);
 

@@ -25,7 +25,7 @@ ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max"
 
 # every entry point include/wrsn_hip.h declares
 EXPORTS = ("wrsn_create", "wrsn_destroy", "wrsn_set_stream", "wrsn_set_scenario", "wrsn_reset", "wrsn_step",
-           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
+           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_set_timing", "wrsn_kernel_times", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
            "wrsn_last_error",
            "wrsn_version")
 
@@ -89,6 +89,10 @@ def bind(lib):
     lib.wrsn_rollout_record.restype = C.c_int
     lib.wrsn_rollout_collect.argtypes = [vp, C.POINTER(WrsnTransitionBuffers), C.POINTER(WrsnStepOut)]
     lib.wrsn_rollout_collect.restype = C.c_int
+    lib.wrsn_set_timing.argtypes = [vp, C.c_int32]
+    lib.wrsn_set_timing.restype = C.c_int
+    lib.wrsn_kernel_times.argtypes = [vp, vp]
+    lib.wrsn_kernel_times.restype = C.c_int
     lib.wrsn_render.argtypes = [vp, vp, vp]
     lib.wrsn_render.restype = C.c_int
     lib.wrsn_peek.argtypes = [vp, C.c_int32, vp]
@@ -227,6 +231,15 @@ class RawHandle:
     def rollout_collect(self, buffers, **out_ptrs):
         o = self._out(**out_ptrs)
         check(self.lib, self.lib.wrsn_rollout_collect(self._h, C.byref(buffers), C.byref(o)))
+
+    def set_timing(self, on):
+        check(self.lib, self.lib.wrsn_set_timing(self._h, 1 if on else 0))
+
+    def kernel_times(self):
+        import numpy as np
+        a = np.zeros(4, dtype=np.float32)
+        check(self.lib, self.lib.wrsn_kernel_times(self._h, a.ctypes.data))
+        return {"order_ms": float(a[0]), "step_ms": float(a[1]), "continuation_ms": float(a[2]), "obs_ms": float(a[3])}
 
     def render(self, agent_ptr, obs_ptr):
         check(self.lib, self.lib.wrsn_render(self._h, C.c_void_p(agent_ptr), C.c_void_p(obs_ptr)))

@@ -64,6 +64,9 @@ struct wrsn_handle {
     int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
+    int timing;                // record HIP events around the kernels of every wrsn_step (wrsn_set_timing)
+    hipEvent_t ev[5];          // before the order kernels, after them, after the step kernel, after the continuation, after the observation
+    int ev_ok, ev_obs;         // events created / the last call rendered an observation
     int bp2;                   // B rounded up to a power of two when the launch order is sorted on the device (B <= 8192), else 0
     std::vector<void*> allocs;
     WrsnDev* d_dev;            // device copy of `dev`: the environment kernels read it through the constant cache
@@ -109,11 +112,14 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     dim3 grid(nenv), block(64);
     long long epoch = 0;
     if (budget > 0) epoch = ++h->epoch;                        // parity selects the hand-off list of the two-launch variant
+    const bool timed = (mode == WRSN_MODE_STEP) && h->timing && h->ev_ok;
+    if (timed) (void)hipEventRecord(h->ev[0], h->stream);
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
         hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
         hipLaunchKernelGGL(wrsn_sort_kernel, dim3(1), dim3(WRSN_SORT_THREADS), (size_t)h->bp2 * sizeof(uint32_t), h->stream, h->dev, h->bp2);
     }
+    if (timed) (void)hipEventRecord(h->ev[1], h->stream);
     // A budgeted step is two launches: the lean variant of the step kernel over all environments (no code for the level BFS,
     // the routing rebuild and the packet-exact second: no scratch memory), then the full variant over the few environments
     // the lean one stopped in front of such a service (hand-off list; the other blocks leave at once).
@@ -122,6 +128,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     else if (budget > 0 && h->split) {                                                                                 \
         hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 1);                                         \
+        if (timed) (void)hipEventRecord(h->ev[2], h->stream);                                                          \
         hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv), block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 2);                                         \
     } else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
@@ -135,6 +142,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     default: return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane");
     }
 #undef WRSN_LAUNCH
+    if (timed) { if (!(budget > 0 && h->split)) (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -190,7 +198,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     DeviceGuard guard_(cfg->device);
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
-    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1;
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0;
     { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
     {   // budget taper over the launch order (units of slots / 8 blocks): start 8 = after the first `slots` blocks, length 16 = down to
         // zero over two times `slots` blocks (the floor of a quarter applies first); WRSN_TAPER="start,len" overrides (diagnostic)
@@ -262,6 +270,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
 void wrsn_destroy(wrsn_t* h) {
     if (!h) return;
     DeviceGuard guard_(h->cfg.device);
+    if (h->ev_ok) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -345,7 +354,35 @@ int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t 
     o.now = out->now; o.obs = out->obs; o.status = out->status;
     int rc = launch_env(h, WRSN_MODE_STEP, 0, h->dev.B, agent_id, action, auto_reset, nullptr, o);
     if (rc) return rc;
-    if (out->obs) return launch_obs(h, h->dev.render_agent, out->obs);
+    if (out->obs) {
+        rc = launch_obs(h, h->dev.render_agent, out->obs);
+        if (h->timing && h->ev_ok) { (void)hipEventRecord(h->ev[4], h->stream); h->ev_obs = 1; }
+        return rc;
+    }
+    return WRSN_OK;
+}
+
+int wrsn_set_timing(wrsn_t* h, int32_t on) {
+    if (!h) return fail(WRSN_ERR_ARG, "null handle");
+    WRSN_ON_DEVICE(h);
+    if (on && !h->ev_ok) {
+        for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+        h->ev_ok = 1;
+    }
+    h->timing = on ? 1 : 0;
+    return WRSN_OK;
+}
+
+int wrsn_kernel_times(wrsn_t* h, float* ms) {
+    if (!h || !ms) return fail(WRSN_ERR_ARG, "null argument");
+    if (!h->ev_ok || !h->timing) return fail(WRSN_ERR_STATE, "wrsn_set_timing(h, 1) first");
+    WRSN_ON_DEVICE(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms[0], h->ev[0], h->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms[1], h->ev[1], h->ev[2]));
+    HIPCHK(hipEventElapsedTime(&ms[2], h->ev[2], h->ev[3]));
+    if (h->ev_obs) HIPCHK(hipEventElapsedTime(&ms[3], h->ev[3], h->ev[4]));
     return WRSN_OK;
 }
 
