@@ -117,7 +117,20 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
         hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
-        hipLaunchKernelGGL(wrsn_sort_kernel, dim3(1), dim3(WRSN_SORT_THREADS), (size_t)h->bp2 * sizeof(uint32_t), h->stream, h->dev, h->bp2);
+        {
+            const int kpt = h->bp2 / WRSN_SORT_THREADS;        // keys per thread of the sort workgroup (0, 1: plain network in LDS)
+            const size_t lb = (size_t)h->bp2 * sizeof(uint32_t);
+#define WRSN_SORT(K_) hipLaunchKernelGGL((wrsn_sort_kernel<K_>), dim3(1), dim3(WRSN_SORT_THREADS), lb, h->stream, h->dev, h->bp2)
+            switch (kpt) {
+            case 2: WRSN_SORT(2); break;
+            case 4: WRSN_SORT(4); break;
+            case 8: WRSN_SORT(8); break;
+            case 16: WRSN_SORT(16); break;
+            case 32: WRSN_SORT(32); break;
+            default: WRSN_SORT(1); break;
+            }
+#undef WRSN_SORT
+        }
     }
     if (timed) (void)hipEventRecord(h->ev[1], h->stream);
     // A budgeted step is two launches: the lean variant of the step kernel over all environments (no code for the level BFS,

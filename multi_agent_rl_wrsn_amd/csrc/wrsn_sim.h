@@ -2170,24 +2170,79 @@ __global__ void __launch_bounds__(256) wrsn_estimate_kernel(WrsnDev d, const int
 #ifndef WRSN_SORT_THREADS
 #define WRSN_SORT_THREADS 1024                               // the CPU emulator of tests/emu runs at most 256 fibers per block and says so
 #endif
+// Bitonic network over BP2 keys, one workgroup.  A thread owns K = BP2 / threads consecutive keys in registers: compare-exchanges
+// with a stride below K stay inside the thread, strides below 64 K are exchanged with a lane of the same wave (no barrier), only
+// the strides of 64 K keys and more go through LDS behind a workgroup barrier (10 of the 78 stages at 4096 keys on 1024 threads).
+// K = 1 is the plain network in LDS (small batches).
+template <int K>
 __global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d, int BP2) {
     extern __shared__ double smem[];
-    unsigned* k = (unsigned*)smem;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < BP2; i += WRSN_SORT_THREADS) k[i] = d.order_key[i];
-    __syncthreads();
-    for (int size = 2; size <= BP2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < BP2 / 2; i += WRSN_SORT_THREADS) {
-                const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;     // pair (lo, lo + stride) of the bitonic network
-                const bool up = (lo & size) == 0;
-                const unsigned a = k[lo], b = k[hi];
-                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+    unsigned* lds = (unsigned*)smem;
+    const int tid = threadIdx.x, T = WRSN_SORT_THREADS;
+    if (K == 1) {
+        for (int i = tid; i < BP2; i += T) lds[i] = d.order_key[i];
+        __syncthreads();
+        for (int size = 2; size <= BP2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < BP2 / 2; i += T) {
+                    const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const unsigned a = lds[lo], b = lds[hi];
+                    if ((a > b) == up) { lds[lo] = b; lds[hi] = a; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
+        for (int i = tid; i < BP2; i += T) d.order[i] = (int)(lds[i] & 0x1FFFu);
+        return;
+    }
+    unsigned k[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) k[j] = d.order_key[tid * K + j];
+    for (int size = 2; size <= BP2; size <<= 1) {
+        for (int stride = size >> 1; stride >= K; stride >>= 1) {
+            if (stride < 64 * K) {                           // partner key j of lane (lane ^ stride / K): same wave, no barrier
+                const int lane_x = stride / K;
+                const bool upper = (tid & lane_x) != 0;      // this thread holds the higher index of every pair
+                const bool up = (((tid * K) & ~stride) & size) == 0;     // size > stride >= K: the same for all keys of the thread
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const unsigned mine = k[j], other = (unsigned)__shfl_xor((int)mine, lane_x);
+                    const unsigned lo_v = mine < other ? mine : other, hi_v = mine < other ? other : mine;
+                    k[j] = (upper == up) ? hi_v : lo_v;
+                }
+            } else {                                         // across waves: through LDS
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < K; ++j) lds[tid * K + j] = k[j];
+                __syncthreads();
+                const bool upper = ((tid * K) & stride) != 0;
+                const bool up = (((tid * K) & ~stride) & size) == 0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const unsigned mine = k[j], other = lds[(tid * K + j) ^ stride];
+                    const unsigned lo_v = mine < other ? mine : other, hi_v = mine < other ? other : mine;
+                    k[j] = (upper == up) ? hi_v : lo_v;
+                }
+            }
+        }
+        // the strides below K of this pass: both keys of a pair in this thread (compile-time register indices)
+#pragma unroll
+        for (int st = K / 2; st >= 1; st >>= 1) {
+            if (st < size) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    if (!(j & st)) {
+                        const bool up = (((tid * K + j) & size) == 0);
+                        const unsigned a = k[j], b = k[j | st];
+                        const bool sw = (a > b) == up;
+                        k[j] = sw ? b : a; k[j | st] = sw ? a : b;
+                    }
+                }
+            }
         }
     }
-    for (int i = tid; i < BP2; i += WRSN_SORT_THREADS) d.order[i] = (int)(k[i] & 0x1FFFu);
+#pragma unroll
+    for (int j = 0; j < K; ++j) d.order[tid * K + j] = (int)(k[j] & 0x1FFFu);
 }
 
 // ------------------------------------------------------------------ topology kernel (one wave per environment)

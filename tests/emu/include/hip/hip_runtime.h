@@ -71,7 +71,7 @@ inline T emu_exchange(T v, int src_lane) {
     std::memcpy(emu_slots[p][threadIdx.x], &v, sizeof(T));
     emu_barrier();                           // flips emu_parity once all lanes have arrived
     T r;
-    std::memcpy(&r, emu_slots[p][src_lane & 63], sizeof(T));
+    std::memcpy(&r, emu_slots[p][(threadIdx.x & ~63u) | (unsigned)(src_lane & 63)], sizeof(T));   // the source lane of the caller's own wavefront
     return r;
 }
 template <typename T> inline T __shfl(T v, int src) { return emu_exchange(v, src); }

@@ -388,3 +388,41 @@ def test_emulated_observation_at_other_map_sizes(G):
             break
         assert int(ev.agent_id[0]) == r["agent_id"]
         assert np.max(np.abs(ev.obs[0] - r["state"])) <= 1e-5 * max(1.0, np.abs(r["state"]).max()), k
+
+
+def test_emulated_launch_order_with_many_environments():
+    """More environments than sort threads x 2 (the register / wave-shuffle / LDS variant of the launch-order sort): every environment
+    is handled exactly once per launch and the requests equal those of the same environments stepped one by one."""
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    B, M = 520, 2
+    uniq = [synth_scenario(600 + u, 24, 16) for u in range(8)]
+    scs = [uniq[e % 8] for e in range(B)]
+    ev = _emu(scs, DEFAULT_MC_SPEC, M, map_size=8)
+    ev.h.set_step_budget(50)
+    ev.reset(with_obs=False)
+    rng = np.random.RandomState(12)
+    acts = rng.rand(3, 8, 3)
+    tab = np.zeros((B, M + 3))
+    hist = [[] for _ in range(B)]
+    nxt = np.zeros(B, dtype=int); busy = np.zeros(B, dtype=bool)
+    cur = ev.agent_id.copy()
+    for it in range(400):
+        done = (nxt >= 3) & ~busy
+        if done.all(): break
+        ids = cur.copy(); ids[done] = -2
+        act = np.stack([acts[min(nxt[e], 2), e % 8] for e in range(B)])
+        ev.step(ids, act, with_obs=False)
+        ev.h.rollout_table(tab.ctypes.data, True)
+        assert tab[:, M + 2].max() <= 1.0
+        for e in range(B):
+            if done[e]: continue
+            if not busy[e]: nxt[e] += 1
+            busy[e] = ev.status[e] == 4
+            if not busy[e]:
+                assert tab[e, M + 2] == 1.0
+                hist[e].append((int(ev.agent_id[e]), float(ev.now[e]), int(ev.terminal[e])))
+                if ev.terminal[e] or ev.agent_id[e] < 0: nxt[e] = 3
+        cur = ev.agent_id.copy()
+    assert ((nxt >= 3) & ~busy).all()
+    for e in range(8, B):                                    # replicas of a scenario with the same actions agree
+        assert hist[e] == hist[e % 8], e
