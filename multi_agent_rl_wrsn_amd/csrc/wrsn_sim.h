@@ -253,6 +253,7 @@ struct Sim {
     double teps;                                             // energy margin of the "may a node run dry" tests
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
+    int fit_dirty;                                           // a grid service ran since last_minfit was evaluated (wave-uniform)
     int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has
     double last_minfit;
     WRSN_PROF_DECL
@@ -418,7 +419,7 @@ struct Sim {
         net_phase = wu(dy->net_phase); net_active = wu(dy->net_active); node_phase = wu(dy->node_phase); alive = wu(dy->alive);
         levels_dirty = wu(dy->levels_dirty); cache_dirty = wu(dy->cache_dirty); irreg = wu(dy->irreg); ring_len = wu(dy->ring_len);
         ring_head = wu(dy->ring_head); safe_ticks = wu(dy->safe_ticks); frozen = wu(dy->frozen);
-        log_pending = wu(dy->log_pending);
+        log_pending = wu(dy->log_pending); fit_dirty = wu(dy->fit_dirty);
         const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = ga[w];
         const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)STH();
@@ -453,7 +454,7 @@ struct Sim {
             dy->net_phase = net_phase; dy->net_active = net_active; dy->node_phase = node_phase; dy->alive = alive;
             dy->levels_dirty = levels_dirty; dy->cache_dirty = cache_dirty; dy->irreg = irreg; dy->ring_len = ring_len;
             dy->ring_head = ring_head; dy->safe_ticks = safe_ticks; dy->frozen = frozen; dy->n_connected = SREQ()[2];
-            dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending; dy->susp = susp;
+            dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending; dy->susp = susp; dy->fit_dirty = fit_dirty;
         }
         uint64_t* ga = (uint64_t*)dy->ag; const uint64_t* la = (const uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) ga[w] = la[w];
@@ -1856,7 +1857,7 @@ struct Sim {
             work += 16;
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
-            case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
+            case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) fit_dirty = 1; grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { svc = precheck(arg); } break;
             case REQ_CONN: { conn_build(arg); } break;
             default: break;
@@ -1932,7 +1933,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     __syncthreads();
     s.run(true, ec->warm_up_time);                           // env.run(until=warm_up_time): stops before that instant's NORMAL events
     double fit = s.min_fitness();
-    s.last_minfit = fit;
+    s.last_minfit = fit; s.fit_dirty = 0;
     if (lane == 0) {
         for (int m = 0; m < s.M; ++m) {                      // WRSN.py:59-64
             s.SAG()[m].action[0] = (ec->bs[0] - ec->frame[0]) / (ec->frame[1] - ec->frame[0]);
@@ -2065,7 +2066,9 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             susp = s.run(false, 0.0, budget) ? 1 : 0;        // env.run(until=general_process)
             if (susp) { }
             else if (s.alive == 0) terminal = 1;             // WRSN.py:312-320
-            else { WRSN_P4_MARK(k2_) fit = s.min_fitness(); s.last_minfit = fit; WRSN_P4_MARK(k3_)
+            else if (!s.fit_dirty) fit = s.last_minfit;      // no grid item ran since the last evaluation (a return at the instant of the
+                                                             // call: the bookkeeping steps at t = warm_up_time): node state, hence fitness, unchanged
+            else { WRSN_P4_MARK(k2_) fit = s.min_fitness(); s.last_minfit = fit; s.fit_dirty = 0; WRSN_P4_MARK(k3_)
 #if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
                 s.prof_[15] += k3_ - k2_;
 #endif
