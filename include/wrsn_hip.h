@@ -204,6 +204,13 @@ int wrsn_render(wrsn_t *h, const int32_t *agent_id, float *obs);
 /* Copy internal state to HOST memory (parity tests, `net` / `agents` views).  Synchronises. */
 int wrsn_peek(wrsn_t *h, int32_t what, void *dst);
 
+/* Observation reuse.  Map 1 of get_state (WRSN.py:137-147) depends on node state only, maps 2..4 on the asking charger.  With
+ * on != 0 the caller promises that an `obs` row the library wrote keeps its content until the library writes it again (same buffer
+ * passed call after call, never modified, never re-allocated at the same address with other content); the render pass then leaves map 1
+ * of a row alone when no simulated second has passed since it rendered that row at that address (a WRSN.step that returns at the
+ * instant it was called) and writes only maps 2..4.  Results are bit-identical; default off. */
+int wrsn_set_obs_reuse(wrsn_t *h, int32_t on);
+
 /* Per-kernel timing of the step path with HIP events recorded on the handle's stream (the stream the kernels are launched on).
  * wrsn_set_timing(h, 1) makes every following wrsn_step record four events; wrsn_kernel_times waits for the last call and
  * returns, in milliseconds: ms[0] launch-order kernels (work estimate + sort), ms[1] step kernel, ms[2] continuation launch of the

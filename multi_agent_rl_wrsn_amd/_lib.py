@@ -25,7 +25,7 @@ ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max"
 
 # every entry point include/wrsn_hip.h declares
 EXPORTS = ("wrsn_create", "wrsn_destroy", "wrsn_set_stream", "wrsn_set_scenario", "wrsn_reset", "wrsn_step",
-           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_set_timing", "wrsn_kernel_times", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
+           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_set_obs_reuse", "wrsn_set_timing", "wrsn_kernel_times", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
            "wrsn_last_error",
            "wrsn_version")
 
@@ -89,6 +89,8 @@ def bind(lib):
     lib.wrsn_rollout_record.restype = C.c_int
     lib.wrsn_rollout_collect.argtypes = [vp, C.POINTER(WrsnTransitionBuffers), C.POINTER(WrsnStepOut)]
     lib.wrsn_rollout_collect.restype = C.c_int
+    lib.wrsn_set_obs_reuse.argtypes = [vp, C.c_int32]
+    lib.wrsn_set_obs_reuse.restype = C.c_int
     lib.wrsn_set_timing.argtypes = [vp, C.c_int32]
     lib.wrsn_set_timing.restype = C.c_int
     lib.wrsn_kernel_times.argtypes = [vp, vp]
@@ -231,6 +233,9 @@ class RawHandle:
     def rollout_collect(self, buffers, **out_ptrs):
         o = self._out(**out_ptrs)
         check(self.lib, self.lib.wrsn_rollout_collect(self._h, C.byref(buffers), C.byref(o)))
+
+    def set_obs_reuse(self, on):
+        check(self.lib, self.lib.wrsn_set_obs_reuse(self._h, 1 if on else 0))
 
     def set_timing(self, on):
         check(self.lib, self.lib.wrsn_set_timing(self._h, 1 if on else 0))

@@ -64,6 +64,7 @@ struct wrsn_handle {
     int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
+    int obs_reuse;             // wrsn_set_obs_reuse: the caller keeps the observation rows the library wrote
     int timing;                // record HIP events around the kernels of every wrsn_step (wrsn_set_timing)
     hipEvent_t ev[5];          // before the order kernels, after them, after the step kernel, after the continuation, after the observation
     int ev_ok, ev_obs;         // events created / the last call rendered an observation
@@ -161,7 +162,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
 }
 
 int launch_obs(wrsn_handle* h, const int32_t* agent_id, float* obs) {
-    hipLaunchKernelGGL(wrsn_obs_kernel, dim3(h->dev.B), dim3(256), h->lds_obs, h->stream, h->dev, agent_id, obs);
+    hipLaunchKernelGGL(wrsn_obs_kernel, dim3(h->dev.B), dim3(256), h->lds_obs, h->stream, h->dev, agent_id, obs, h->obs_reuse);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -211,7 +212,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     DeviceGuard guard_(cfg->device);
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
-    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0;
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0;
     { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
     {   // budget taper over the launch order (units of slots / 8 blocks): start 8 = after the first `slots` blocks, length 16 = down to
         // zero over two times `slots` blocks (the floor of a quarter applies first); WRSN_TAPER="start,len" overrides (diagnostic)
@@ -372,6 +373,12 @@ int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t 
         if (h->timing && h->ev_ok) { (void)hipEventRecord(h->ev[4], h->stream); h->ev_obs = 1; }
         return rc;
     }
+    return WRSN_OK;
+}
+
+int wrsn_set_obs_reuse(wrsn_t* h, int32_t on) {
+    if (!h) return fail(WRSN_ERR_ARG, "null handle");
+    h->obs_reuse = on ? 1 : 0;
     return WRSN_OK;
 }
 

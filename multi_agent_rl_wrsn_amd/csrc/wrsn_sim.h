@@ -253,7 +253,7 @@ struct Sim {
     double teps;                                             // energy margin of the "may a node run dry" tests
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
-    int fit_dirty;                                           // a grid service ran since last_minfit was evaluated (wave-uniform)
+    int fit_dirty, map1_valid;                               // a grid service ran since last_minfit was evaluated / map 1 of the observation still stands (wave-uniform)
     int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has
     double last_minfit;
     WRSN_PROF_DECL
@@ -419,7 +419,7 @@ struct Sim {
         net_phase = wu(dy->net_phase); net_active = wu(dy->net_active); node_phase = wu(dy->node_phase); alive = wu(dy->alive);
         levels_dirty = wu(dy->levels_dirty); cache_dirty = wu(dy->cache_dirty); irreg = wu(dy->irreg); ring_len = wu(dy->ring_len);
         ring_head = wu(dy->ring_head); safe_ticks = wu(dy->safe_ticks); frozen = wu(dy->frozen);
-        log_pending = wu(dy->log_pending); fit_dirty = wu(dy->fit_dirty);
+        log_pending = wu(dy->log_pending); fit_dirty = wu(dy->fit_dirty); map1_valid = wu(dy->map1_valid);
         const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = ga[w];
         const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)STH();
@@ -454,7 +454,7 @@ struct Sim {
             dy->net_phase = net_phase; dy->net_active = net_active; dy->node_phase = node_phase; dy->alive = alive;
             dy->levels_dirty = levels_dirty; dy->cache_dirty = cache_dirty; dy->irreg = irreg; dy->ring_len = ring_len;
             dy->ring_head = ring_head; dy->safe_ticks = safe_ticks; dy->frozen = frozen; dy->n_connected = SREQ()[2];
-            dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending; dy->susp = susp; dy->fit_dirty = fit_dirty;
+            dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending; dy->susp = susp; dy->fit_dirty = fit_dirty; dy->map1_valid = map1_valid;
         }
         uint64_t* ga = (uint64_t*)dy->ag; const uint64_t* la = (const uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) ga[w] = la[w];
@@ -1857,7 +1857,7 @@ struct Sim {
             work += 16;
             if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
             switch (req) {
-            case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) fit_dirty = 1; grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
+            case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) fit_dirty = 1; map1_valid = 0; grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { svc = precheck(arg); } break;
             case REQ_CONN: { conn_build(arg); } break;
             default: break;
@@ -1933,7 +1933,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     __syncthreads();
     s.run(true, ec->warm_up_time);                           // env.run(until=warm_up_time): stops before that instant's NORMAL events
     double fit = s.min_fitness();
-    s.last_minfit = fit; s.fit_dirty = 0;
+    s.last_minfit = fit; s.fit_dirty = 0; s.map1_valid = 0;
     if (lane == 0) {
         for (int m = 0; m < s.M; ++m) {                      // WRSN.py:59-64
             s.SAG()[m].action[0] = (ec->bs[0] - ec->frame[0]) / (ec->frame[1] - ec->frame[0]);
@@ -2006,7 +2006,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
       s.prof_[16] += k1_ - k0_; s.prof_[18] += k0_ - kt0_;
 #endif
     }
-    if (do_reset) s.dirty = 7;                             // the snapshot goes to the live arrays in full
+    if (do_reset) { s.dirty = 7; s.map1_valid = 0; }       // the snapshot goes to the live arrays in full; a rendered map 1 no longer stands
     const int64_t ticks0 = s.n_ticks;
     int terminal = 0, susp = 0;
     if (do_reset) {
@@ -2529,7 +2529,10 @@ typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
 // value of the first active lane for the whole wave (the CPU emulator of tests/emu supplies its own rendezvous)
 WDEV int wrsn_wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
-__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs) {
+// `reuse` (wrsn_set_obs_reuse): map 1 depends on node state only.  When no grid item ran since it was last rendered into this very row
+// (a WRSN.step that returns at the instant it was called -- 40 % of the steps of short episodes -- or the same charger asked twice),
+// the row still holds it: only maps 2..4, which depend on the asking charger, are written.
+__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs, int reuse) {
     extern __shared__ double smem[];
     const int env = blockIdx.x, tid = threadIdx.x;
     const int aid = agent_id[env];
@@ -2553,6 +2556,8 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     const double hX = ec->charging_range / W, hY = ec->charging_range / H;
     const float inv2hx = (float)(-1.0 / (2.0 * hX * hX)), inv2hy = (float)(-1.0 / (2.0 * hY * hY));
     float* out = obs + (size_t)env * 4 * G * G;
+    WrsnEnvDyn* dyw = d.live.dyn + env;
+    const bool keep1 = reuse && dyw->map1_valid && dyw->map1_ptr == (uint64_t)(uintptr_t)out;   // block-uniform
     // Role of a wave: 0..2 = the 32-row band of map 1 it computes on the matrix cores, 3 = the store wave (rows 96.. of map 1 on the
     // VALU, then maps 2..4).  The roles rotate with the block index so that the (matrix-core-free) store waves of the blocks resident
     // on a CU do not all sit on the same SIMD.
@@ -2574,7 +2579,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
         const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)sag;
         for (int w = tid; w < M * (int)(sizeof(WrsnAgent) / 8); w += 256) la[w] = ga[w];
     }
-    {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
+    if (!keep1) {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
         const double a_b2 = ec->alpha / (ec->beta * ec->beta), thr = ec->threshold, span = ec->capacity - ec->threshold;
         for (int n = tid; n < NP; n += 256) {
             double w = 0.0, cx = 0.0, cy = 0.0;
@@ -2603,7 +2608,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     __syncthreads();                                       // pc / wf ready
-    for (int c = tid; c < NP / WRSN_OBS_CH + 2; c += 256) {
+    if (!keep1) for (int c = tid; c < NP / WRSN_OBS_CH + 2; c += 256) {
         float xlo = 3.0e38f, xhi = -3.0e38f, ylo = 3.0e38f, yhi = -3.0e38f;
         for (int k = 0; k < WRSN_OBS_CH; ++k) {
             const int n = c * WRSN_OBS_CH + k;
@@ -2661,7 +2666,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     const float rx = 6.5f * (float)hX, ry = 6.5f * (float)hY;
     const float band_lo = (float)((row0 + 0.5) * unit), band_hi = (float)((row0 + 31.5) * unit);
     const int nchunk = (N + WRSN_OBS_CH - 1) / WRSN_OBS_CH;
-    const bool mfma_wave = wave < 3 && band;               // rows 0..95 on the matrix cores; wave 3 is the store wave
+    const bool mfma_wave = wave < 3 && band && !keep1;     // rows 0..95 on the matrix cores; wave 3 is the store wave
     if (mfma_wave) {
         const float* pxw = pxb + wave * NS;
         for (int c = 0; c < nchunk; ++c) {
@@ -2734,7 +2739,8 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
         }
     }
     WRSN_OBS_STAMP(4)
-    if (wave == 3) {
+    if (tid == 0 && !keep1) { dyw->map1_valid = 1; dyw->map1_ptr = (uint64_t)(uintptr_t)out; }   // (only consulted with `reuse`)
+    if (wave == 3 && !keep1) {
         // ---- the store wave, part 1.  Rows 96 .. G-1 of map 1 (4 rows at G = 100: a fourth matrix-core band would be 7/8 idle) as
         // rank-1 updates on the VALU: a lane owns columns l and l + 64, four rows at a time in registers; the same Morton order,
         // chunk cut-off (6.5 bandwidths) and float32 fma chain as the matrix-core bands.

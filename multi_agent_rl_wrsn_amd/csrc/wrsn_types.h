@@ -61,7 +61,8 @@ struct WrsnEnvDyn {
     int32_t net_phase, net_active, node_phase, alive;
     int32_t levels_dirty, cache_dirty, irreg, ring_len;
     int32_t ring_head, safe_ticks, frozen, terminal_pending;
-    int32_t fit_dirty, pad3;                 // node state changed (a grid service ran) since last_minfit was evaluated
+    int32_t fit_dirty, map1_valid;           // node state changed (a grid service ran) since last_minfit was evaluated / since map 1 of the
+    uint64_t map1_ptr;                       // observation was rendered into the row at this address (wrsn_set_obs_reuse; written by the observation kernel)
     int32_t n_connected, error, log_pending, susp;   // susp: WRSN.step in flight (work budget of a launch used up)
     // the `|` conditions of the step in flight (WRSN.py:307-311); only meaningful while susp != 0
     double cond_time[WRSN_MAX_MC + 1]; int64_t cond_seq[WRSN_MAX_MC + 1];

@@ -27,6 +27,9 @@ class VecWRSN:
     agent_type: dict / YAML path of the charger parameters (mc_types/default.yaml), None = shipped defaults
     num_agent : number of mobile chargers per environment (`num_agent`, WRSN.py:26)
     auto_reset: an environment whose last return was terminal is reset by the next `step` (status 3)
+    reuse_obs : the `state` tensor the requests return is owned by this object and must be treated as READ-ONLY (clone before modifying
+                it): map 1 of a row -- the node map, which depends on node state only -- is then not re-rendered by a step that returns at the
+                instant it was called (`wrsn_set_obs_reuse`); bit-identical results.  False re-renders every row in full.
     step_budget: 0 = every `step` runs each WRSN.step to its end (the reference's blocking call).  > 0 bounds the work
                 of one launch per environment (units of ~400 cycles counted per simulated second / service / exact second): an
                 environment whose step is still in flight reports status 4 / agent_id -1 and simply goes on in the
@@ -35,7 +38,7 @@ class VecWRSN:
     """
 
     def __init__(self, scenarios, agent_type=None, num_agent=3, map_size=100, warm_up_time=100, device="cuda:0",
-                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0):
+                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0, reuse_obs=True):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("VecWRSN needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -62,6 +65,8 @@ class VecWRSN:
             self._h = _lib.RawHandle(lib, self.num_env, self.n_node, self.n_target, self.num_agent, self.map_size,
                                      self.warm_up_time, dev_index, max_degree, max_cover)
             self._h.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            if reuse_obs and self.render:
+                self._h.set_obs_reuse(True)
             self.step_budget = int(step_budget)
             if self.step_budget:
                 self._h.set_step_budget(self.step_budget)

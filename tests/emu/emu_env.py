@@ -29,6 +29,7 @@ class EmuVec:
         self.M, self.G = num_agent, map_size
         self.h = _lib.RawHandle(emu_lib(), self.B, self.N, self.T, num_agent, map_size, warm_up_time, 0, max_degree, max_cover)
         self.h.set_scenarios(scenarios, mc_spec)
+        self.h.set_obs_reuse(True)                            # like VecWRSN: the same obs array is passed call after call and never modified
         B, G = self.B, self.G
         self.agent_id = np.full(B, -1, dtype=np.int32); self.reward = np.zeros(B); self.terminal = np.zeros(B, dtype=np.uint8)
         self.now = np.zeros(B); self.status = np.zeros(B, dtype=np.int32); self.obs = np.zeros((B, 4, G, G), dtype=np.float32)

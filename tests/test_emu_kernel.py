@@ -426,3 +426,32 @@ def test_emulated_launch_order_with_many_environments():
     assert ((nxt >= 3) & ~busy).all()
     for e in range(8, B):                                    # replicas of a scenario with the same actions agree
         assert hist[e] == hist[e % 8], e
+
+
+def test_emulated_observation_reuse_is_bit_identical():
+    """wrsn_set_obs_reuse: map 1 of a row is left alone when no simulated second passed since it was rendered there -- the result
+    equals the full render bit for bit, a render into another buffer in between does not confuse it, and a caller that does
+    modify its buffer (reuse off) still gets full renders."""
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    scs = [synth_scenario(50 + e, 70, 60) for e in range(3)]
+    M, G = 3, 20
+    a = _emu(scs, DEFAULT_MC_SPEC, M, map_size=G); b = _emu(scs, DEFAULT_MC_SPEC, M, map_size=G)
+    b.h.set_obs_reuse(False)
+    a.reset(); b.reset()
+    assert np.array_equal(a.obs, b.obs)
+    rng = np.random.RandomState(8)
+    other = np.zeros_like(a.obs)
+    zero_time = 0
+    for k in range(14):
+        act = rng.rand(3, 3)
+        ids = a.agent_id.copy(); now0 = a.now.copy()
+        b.obs[:] = -5.0                                       # the caller of b scribbles over its buffer: b renders in full every time
+        a.step(ids, act, auto_reset=True); b.step(ids, act, auto_reset=True)
+        zero_time += int(((a.now == now0) & (a.status == 0) & (a.agent_id >= 0)).sum())
+        rows = a.agent_id >= 0
+        assert np.array_equal(a.obs[rows], b.obs[rows]), k
+        if k % 3 == 1:                                        # a render elsewhere moves the remembered address: the next one is full again
+            agents = np.maximum(a.agent_id, 0).astype(np.int32)
+            a.h.render(agents.ctypes.data, other.ctypes.data)
+            assert np.array_equal(other[rows][:, 0], a.obs[rows][:, 0])
+    assert zero_time >= 3
