@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=2)
+    ap.add_argument("--warmup-iters", type=int, default=1, help="untimed iterations first (MIOpen kernel search for every new convolution shape)")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--batch-size", type=int, default=512)
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--updates", type=int, default=5)
     ap.add_argument("--step-budget", type=int, default=1500)
     ap.add_argument("--infer-chunk", type=int, default=512)
+    ap.add_argument("--inference-dtype", default=None, choices=[None, "bf16", "fp16"], help="reduced-precision roll-out inference (update stays float32)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -37,16 +39,21 @@ def main():
     B, N, M = args.envs, args.nodes, 3
     env = VecWRSN([synth_scenario(e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev))
     algo = BatchedIPPO(dict(batch_size=args.batch_size, minibatch_size=args.minibatch_size, n_updates_per_iteration=args.updates), env,
-                       capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk)
+                       capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk, inference_dtype=args.inference_dtype)
+    if args.warmup_iters > 0:
+        algo.train(args.warmup_iters - 1)
+        for k in algo.timers: algo.timers[k] = 0 if isinstance(algo.timers[k], int) else 0.0
+    torch.cuda.synchronize(dev)
     c0 = env.counters(); t0 = time.perf_counter()
     rows = algo.train(args.iters - 1)                          # train() runs iterations 0..n inclusive like the reference's loop (IPPO.py:220)
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     c1 = env.counters(); t = algo.timers; it = args.iters
     steps = c1["env_steps"] - c0["env_steps"]
-    out = {"metric": "IPPO roll-out + train, 4096 envs x 200 nodes x 3 MC, 1 MI355X (BASELINE configs[2])", "iterations": it,
+    out = {"metric": "IPPO roll-out + train, 4096 envs x 200 nodes x 3 MC, 1 MI355X (BASELINE configs[2])", "iterations": it, "warmup_iterations": args.warmup_iters,
            "config": {"workload": "%d envs x %d nodes x %d MC, UNet actor + CNN critic per charger, density-map actions, batch %d / minibatch %d / %d epochs" %
-                      (B, N, M, args.batch_size, args.minibatch_size, args.updates), "step_budget": args.step_budget},
+                      (B, N, M, args.batch_size, args.minibatch_size, args.updates), "step_budget": args.step_budget,
+                      "policy": "float32, channels-last%s" % ("" if not args.inference_dtype else ", %s roll-out inference" % args.inference_dtype)},
            "per_iteration_s": {"environment": t["env_s"] / it, "policy_inference": t["policy_s"] / it, "rollout_glue": t["glue_s"] / it, "ppo_update": t["train_s"] / it,
                                "wall": wall / it},
            "launches_per_iteration": t["launches"] / it, "requests_served": t["requests"], "env_steps": steps,

@@ -219,7 +219,7 @@ class PPOLearner:
                   over the ranks with ONE all-reduce per minibatch (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).
                   Parameters and BatchNorm buffers are broadcast from rank 0 at construction."""
 
-    def __init__(self, args, num_agent, map_size, device, model_path=None, infer_chunk=1024, process_group=None):
+    def __init__(self, args, num_agent, map_size, device, model_path=None, infer_chunk=1024, process_group=None, inference_dtype=None):
         torch = _torch()
         self.torch = torch
         self.num_agent = int(num_agent)
@@ -231,8 +231,15 @@ class PPOLearner:
                   "vf_coef", "gae_lambda", "norm_adv", "max_grad_norm"):
             setattr(self, k, a[k])
         UNet, CNNCritic = build_networks(self.map_size)
-        self.actors = [UNet().to(self.device) for _ in range(self.num_agent)]
-        self.critics = [CNNCritic().to(self.device) for _ in range(self.num_agent)]
+        # channels-last weights and activations: the same float32 arithmetic, 3.6 x the NCHW convolution throughput of MIOpen on
+        # MI355X (tools/diag_policy.py: 71 vs 20 TFLOP/s for the UNet forward); state_dict keys and shapes are unaffected
+        self._cl = self.device.type == "cuda"
+        mf = dict(memory_format=torch.channels_last) if self._cl else {}
+        self.actors = [UNet().to(self.device).to(**mf) for _ in range(self.num_agent)]
+        self.critics = [CNNCritic().to(self.device).to(**mf) for _ in range(self.num_agent)]
+        # optional reduced-precision INFERENCE (roll-out actions and values only; the update stays float32): "bf16" doubles the
+        # forward throughput again but the roll-out log-probabilities then differ from the float32 ones the update recomputes
+        self.inference_dtype = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16}[inference_dtype]
         self.loggers = [{"i_so_far": 0, "t_so_far": 0, "ep_lifetime": [], "losses": [], "rewards": []} for _ in range(self.num_agent)]
         if model_path is not None:                            # IPPO.py:49-64
             for agent_folder in os.listdir(model_path):
@@ -257,25 +264,40 @@ class PPOLearner:
         outs, lps = [], []
         with torch.no_grad():
             for s in states.split(self.infer_chunk):
-                mean, log_std = self.actors[agent_id](s)
+                # one batch shape for every forward pass (MIOpen searches / compiles its convolution kernels per shape: seconds for each
+                # new one): a short last chunk is filled up by repeating its own rows, whose outputs are dropped
+                r = s.shape[0]
+                if r < self.infer_chunk and self.device.type == "cuda":
+                    s = s.index_select(0, torch.arange(self.infer_chunk, device=s.device) % r)
+                mean, log_std = self._forward(self.actors[agent_id], s, inference=True)
+                mean, log_std = mean[:r].float(), log_std[:r].float()
                 dist = torch.distributions.Normal(mean, log_std.exp())
                 act = dist.sample()
                 outs.append(act); lps.append(dist.log_prob(act).sum((1, 2)))
         return torch.cat(outs), torch.cat(lps)
 
+    def _forward(self, net, x, inference=False):
+        torch = self.torch
+        if self._cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        if inference and self.inference_dtype is not None:
+            with torch.autocast(self.device.type, dtype=self.inference_dtype):
+                return net(x)
+        return net(x)
+
     def evaluate(self, agent_id, batch_states, batch_actions):  # IPPO.py:107-113
         torch = self.torch
-        mean, log_std = self.actors[agent_id](batch_states)
+        mean, log_std = self._forward(self.actors[agent_id], batch_states)
         dist = torch.distributions.Normal(mean, log_std.exp())
         return dist.log_prob(batch_actions).sum((1, 2)), dist.entropy().sum((1, 2))
 
     def get_value(self, agent_id, state):                     # IPPO.py:115-117
-        return self.critics[agent_id](state).sum(1)
+        return self._forward(self.critics[agent_id], state).sum(1)
 
     def _values(self, agent_id, states):
         torch = self.torch
         with torch.no_grad():
-            return torch.cat([self.get_value(agent_id, s) for s in states.split(self.infer_chunk)])
+            return torch.cat([self._forward(self.critics[agent_id], s, inference=True).float().sum(1) for s in states.split(self.infer_chunk)])
 
     def cal_rt_adv(self, id, states, rewards, next_states, terminals):
         """IPPO.py:71-93.  `terminals` follows the reference's convention (the stored flags multiply the bootstrap term);
@@ -362,8 +384,9 @@ class BatchedIPPO(PPOLearner):
     (`density_map=True` environments of runner/IPPO.py:19-21): the actor's G x G output is the action and is turned into the
     3-vector on the device (`VecWRSN.density_to_action`)."""
 
-    def __init__(self, args, env, device=None, model_path=None, capacity=None, infer_chunk=1024, process_group=None, log=None):
-        super().__init__(args, env.num_agent, env.map_size, device if device is not None else env.device, model_path, infer_chunk, process_group)
+    def __init__(self, args, env, device=None, model_path=None, capacity=None, infer_chunk=1024, process_group=None, log=None, inference_dtype=None):
+        super().__init__(args, env.num_agent, env.map_size, device if device is not None else env.device, model_path, infer_chunk, process_group,
+                         inference_dtype)
         self.env = env
         self.buffers = TransitionBuffers(env, capacity or 2 * self.batch_size, env.map_size * env.map_size)
         self.timers = {"env_s": 0.0, "policy_s": 0.0, "glue_s": 0.0, "train_s": 0.0, "launches": 0, "requests": 0}
