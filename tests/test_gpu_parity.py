@@ -626,3 +626,29 @@ def test_batched_ippo_rollout_and_update_smoke():
     t = algo.timers
     assert t["env_s"] > 0 and t["policy_s"] > 0 and t["launches"] >= 1
     env.close()
+
+
+def test_observation_reuse_is_bit_identical_on_device():
+    """wrsn_set_obs_reuse (on in VecWRSN): a batch with reuse and one that re-renders every row in full (reuse_obs=False, and the
+    caller scribbling over its state tensor) return identical observations over whole episodes with auto-reset and a step budget."""
+    torch = _torch()
+    from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
+    B, M = 192, 3
+    scs = [synth_scenario(6100 + e % 48, 200, 200) for e in range(B)]
+    a = VecWRSN(scs, None, M, auto_reset=True, step_budget=800)
+    b = VecWRSN(scs, None, M, auto_reset=True, step_budget=800, reuse_obs=False)
+    g = torch.Generator().manual_seed(4)
+    ra = a.reset(); rb = b.reset()
+    assert torch.equal(ra["state"], rb["state"])
+    n_zero = 0
+    for k in range(40):
+        act = torch.rand((B, 3), generator=g, dtype=torch.float64)
+        now0 = ra["now"].clone()
+        b.state.fill_(-3.0)                                   # b's caller does not keep its buffer
+        ra = a.step(ra["agent_id"].clone(), act); rb = b.step(rb["agent_id"].clone(), act)
+        rows = ra["agent_id"] >= 0
+        assert torch.equal(ra["agent_id"], rb["agent_id"]) and torch.equal(ra["now"], rb["now"])
+        assert torch.equal(ra["state"][rows], rb["state"][rows]), k
+        n_zero += int(((ra["now"] == now0) & (ra["status"] == 0) & rows).sum())
+    assert n_zero > 100                                       # the rows whose map 1 was kept
+    a.close(); b.close()
