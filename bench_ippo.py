@@ -7,7 +7,11 @@ policy-bound -- the UNet forward is ~5 GFLOP per decision against ~1e-3 GFLOP-eq
 Prints ONE JSON line: per training iteration the wall time split into environment launches (VecWRSN.step incl. the
 observation), policy inference (UNet forward + sampling for every environment that carries a request), roll-out glue
 (transition buffers, density map -> action) and the PPO update; env-steps/s of the roll-out alone and with training.
-`python bench.py` stays the headline (random policy) measurement."""
+`python bench.py` stays the headline (random policy) measurement.
+
+Under torchrun (`python -m torch.distributed.run --nproc-per-node N bench_ippo.py`, BASELINE configs[3]: 8 x 4096 environments)
+every rank rolls out its own environment shard, the actor / critic gradients are averaged with one RCCL all-reduce per minibatch
+(`PPOLearner`), the roll-out returns table is all-gathered once per run, and rank 0 prints the line with whole-job totals."""
 import argparse
 import json
 import os
@@ -33,11 +37,14 @@ def main():
     args = ap.parse_args()
     import numpy as np
     import torch
-    from multi_agent_rl_wrsn_amd import BatchedIPPO, VecWRSN, synth_scenario
-    torch.manual_seed(0); np.random.seed(0)
-    dev = torch.device("cuda", 0)
+    from multi_agent_rl_wrsn_amd import BatchedIPPO, RolloutStats, VecWRSN, init_distributed, synth_scenario
+    rank, world, local_rank = init_distributed()
+    dist = torch.distributed if world > 1 else None
+    torch.manual_seed(0); np.random.seed(rank)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
     B, N, M = args.envs, args.nodes, 3
-    env = VecWRSN([synth_scenario(e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev))
+    env = VecWRSN([synth_scenario(rank * B + e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev))
     algo = BatchedIPPO(dict(batch_size=args.batch_size, minibatch_size=args.minibatch_size, n_updates_per_iteration=args.updates), env,
                        capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk, inference_dtype=args.inference_dtype)
     if args.warmup_iters > 0:
@@ -50,7 +57,17 @@ def main():
     wall = time.perf_counter() - t0
     c1 = env.counters(); t = algo.timers; it = args.iters
     steps = c1["env_steps"] - c0["env_steps"]
-    out = {"metric": "IPPO roll-out + train, 4096 envs x 200 nodes x 3 MC, 1 MI355X (BASELINE configs[2])", "iterations": it, "warmup_iterations": args.warmup_iters,
+    table = RolloutStats.gather_table(env.rollout_table())     # the one exchange of the environment path (RCCL all-gather)
+    if dist:
+        tot = torch.tensor([steps], dtype=torch.float64, device=dev); dist.all_reduce(tot); steps_all = float(tot[0])
+        wl = torch.tensor([wall], dtype=torch.float64, device=dev); dist.all_reduce(wl, op=dist.ReduceOp.MAX); wall = float(wl[0])
+    else:
+        steps_all = float(steps)
+    if rank != 0:
+        if dist: dist.destroy_process_group()
+        return
+    out = {"metric": "IPPO roll-out + train, 4096 envs/GPU x 200 nodes x 3 MC (BASELINE configs[2]; configs[3] under torchrun)", "n_gpus": world,
+           "returns_table_rows": int(table.shape[0]), "env_steps_all_ranks": steps_all, "env_steps_per_s_with_training_all_ranks": steps_all / wall, "iterations": it, "warmup_iterations": args.warmup_iters,
            "config": {"workload": "%d envs x %d nodes x %d MC, UNet actor + CNN critic per charger, density-map actions, batch %d / minibatch %d / %d epochs" %
                       (B, N, M, args.batch_size, args.minibatch_size, args.updates), "step_budget": args.step_budget,
                       "policy": "float32, channels-last%s" % ("" if not args.inference_dtype else ", %s roll-out inference" % args.inference_dtype)},
@@ -61,6 +78,7 @@ def main():
            "env_steps_per_s_with_training": steps / wall, "transitions_per_agent": algo.buffers.counts(),
            "last_rows": rows[-M:], "dtype": "f32 policy / f64 physics", "data": "synthetic"}
     print(json.dumps(out, default=float), flush=True)
+    if dist: dist.destroy_process_group()
 
 
 if __name__ == "__main__":
