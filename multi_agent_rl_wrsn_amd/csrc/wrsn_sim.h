@@ -1696,65 +1696,92 @@ struct Sim {
     // Fire charger / condition events in order until the wave has to do something: run the grid up to the next
     // event (REQ_GRID), an O(N) service (REQ_PRECHECK / REQ_CONN), or the run stops (REQ_STOP).
     // The cached "next event" lives in registers while lane 0 runs and in the LDS Scalar block between two services.
+    // Every lane calls scalar_run: lane 0 decides and fires (scalar_iter), the whole wave looks for the next event
+    // (event_scan) whenever lane 0's cached one is spent.  The return value is wave-uniform; *arg, *t_lim_out,
+    // *flags_out and the advanced `now` / `seq` are lane 0's.
     struct EvCache { int valid, kind, idx, prio, uf; double time, t2; int64_t seq; int64_t fired; };
+    WDEV static int lane0(int v) { return __builtin_amdgcn_readlane(v, 0); }
+    WDEV static double lane_f64(double v, int l) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+    }
+
+    // The pending charger-process / condition event with the smallest SimPy key (time, priority, insertion id), and the
+    // earliest time among the others (t2): one lane per candidate -- lanes 0 .. 2M-1 the operate_step processes, the next L
+    // lanes the `|` conditions of the step -- and three wave minima instead of a lane-0 loop over the candidates.
+    WDEV void event_scan(const int L, int& kind, int& idx, double& bt, int& bp, int64_t& bs, double& t2) {
+        const int nth = 2 * M;
+        bool valid = false; double t = WRSN_INF; int pr = 0; int64_t sq = 0; int kd = -1, ix = 0;
+        if (lane < nth) {
+            const int pc = STH()[lane].pc;
+            valid = pc != PC_NONE && pc != PC_FINISHED; t = STH()[lane].time; pr = STH()[lane].prio; sq = STH()[lane].seq; kd = 3; ix = lane;
+        } else if (lane - nth < L) {
+            const int j = lane - nth + 1;
+            valid = SCP()[j] != 0; t = SCT()[j]; pr = WRSN_NORMAL; sq = SCS()[j]; kd = 4; ix = j;
+        }
+        const unsigned long long anyv = __ballot(valid);
+        if (anyv == 0ull) { kind = -1; idx = 0; bt = 0.0; bp = 0; bs = 0; t2 = WRSN_INF; return; }
+        const double tv = valid ? t : WRSN_INF;
+        const double tmin = wv_min(tv);
+        // insertion ids are unique and far below 2^52: (priority, id) orders as one exact double
+        const double k2 = (valid && tv == tmin) ? (double)sq + (double)pr * 4503599627370496.0 : WRSN_INF;
+        const double kmin = wv_min(k2);
+        const unsigned long long win = __ballot(valid && tv == tmin && k2 == kmin);
+        const int w = __popcll((win & (~win + 1ull)) - 1ull);  // the winning lane
+        t2 = wv_min(lane == w ? WRSN_INF : tv);
+        kind = __builtin_amdgcn_readlane(kd, w); idx = __builtin_amdgcn_readlane(ix, w); bp = __builtin_amdgcn_readlane(pr, w);
+        bt = lane_f64(t, w);
+        const unsigned slo = (unsigned)__builtin_amdgcn_readlane((int)(sq & 0xffffffffll), w); const int shi = __builtin_amdgcn_readlane((int)(sq >> 32), w);
+        bs = ((int64_t)shi << 32) | (int64_t)slo;
+    }
+
     WDEV int scalar_run(double svc, bool use_limit, double limit, int* arg, double* t_lim_out, int* flags_out) {
         Scalar* ss = SS();
+        WRSN_PROF_MARK(sr0_)
+        WRSN_P4_MARK(q0_)
         EvCache ev; ev.valid = ss->ev_valid; ev.kind = ss->ev_kind; ev.idx = ss->ev_idx; ev.prio = ss->ev_prio; ev.uf = ss->ev_uf;
         ev.time = ss->ev_time; ev.t2 = ss->ev2_time; ev.seq = ss->ev_seq; ev.fired = 0;
         const int L = ss->L; const int pend0 = ss->pend, pend_idx0 = ss->pend_idx;
-        int pend_out = 0;
-        const int r = scalar_loop(ev, L, pend0, pend_idx0, &pend_out, svc, use_limit, limit, arg, t_lim_out, flags_out);
-        ss->ev_valid = ev.valid; ss->ev_kind = ev.kind; ss->ev_idx = ev.idx; ss->ev_prio = ev.prio; ss->ev_uf = ev.uf;
-        ss->ev_time = ev.time; ss->ev2_time = ev.t2; ss->ev_seq = ev.seq; ss->n_events += ev.fired; ss->pend = pend_out;
+        int pend_out = 0, r = REQ_STOP;
+        if (lane == 0) {
+            switch (pend0) {                                  // finish the item that asked for the service
+            case REQ_PRECHECK: p_init_tail(pend_idx0, svc); ev.valid = 0; break;
+            case REQ_CONN: mc_charge_loop(pend_idx0); ev.valid = 0; break;
+            case REQ_GRID:
+                if (deaths_flag) {                           // a node died: chargers connected to it re-plan on the exact path
+                    for (int i = 0; i < 2 * M; ++i) if (STH()[i].ff == 2 && STH()[i].pc != PC_NONE && STH()[i].pc != PC_FINISHED && SAG()[STH()[i].agent].n_live > 0) ff_fallback(i);
+                    ev.valid = 0;
+                }
+                break;
+            default: break;
+            }
+        }
+        WRSN_P4_MARK(q1_) WRSN_P4_SPAN(8, q0_, q1_)
+        long guard = 0;
+        for (;; ++guard) {                                   // a step spans at most a few thousand seconds
+            if (guard >= 4000000L) { err = -6; r = REQ_STOP; break; }
+            WRSN_P4_CNT(1, 1) WRSN_P4_MARK(q2_)
+            if (lane0(ev.valid) == 0) { WRSN_P4_CNT(3, 1)     // charger / condition state only changes when one of them fires
+                __syncthreads();                             // what lane 0 wrote is what the other lanes read
+                event_scan(L, ev.kind, ev.idx, ev.time, ev.prio, ev.seq, ev.t2);
+                ev.valid = 1; ev.uf = -1;
+                WRSN_P4_MARK(q3_) WRSN_P4_SPAN(2, q2_, q3_)
+            }
+            int rr = -1;
+            if (lane == 0) rr = scalar_iter(ev, L, &pend_out, use_limit, limit, arg, t_lim_out, flags_out);
+            rr = lane0(rr);
+            if (rr >= 0) { r = rr; break; }
+        }
+        if (lane == 0) {
+            ss->ev_valid = ev.valid; ss->ev_kind = ev.kind; ss->ev_idx = ev.idx; ss->ev_prio = ev.prio; ss->ev_uf = ev.uf;
+            ss->ev_time = ev.time; ss->ev2_time = ev.t2; ss->ev_seq = ev.seq; ss->n_events += ev.fired; ss->pend = pend_out;
+        }
         return r;
     }
 
-    WDEV int scalar_loop(EvCache& ev, const int L, const int pend0, const int pend_idx0, int* pend_out, double svc, bool use_limit, double limit,
-                         int* arg, double* t_lim_out, int* flags_out) {
-        WRSN_PROF_MARK(sr0_)
-        WRSN_P4_MARK(q0_)
-        switch (pend0) {                                      // finish the item that asked for the service
-        case REQ_PRECHECK: p_init_tail(pend_idx0, svc); ev.valid = 0; break;
-        case REQ_CONN: mc_charge_loop(pend_idx0); ev.valid = 0; break;
-        case REQ_GRID:
-            if (deaths_flag) {                               // a node died: chargers connected to it re-plan on the exact path
-                for (int i = 0; i < 2 * M; ++i) if (STH()[i].ff == 2 && STH()[i].pc != PC_NONE && STH()[i].pc != PC_FINISHED && SAG()[STH()[i].agent].n_live > 0) ff_fallback(i);
-                ev.valid = 0;
-            }
-            break;
-        default: break;
-        }
-        WRSN_P4_MARK(q1_) WRSN_P4_SPAN(8, q0_, q1_)
-        for (long guard = 0; guard < 4000000L; ++guard) {   // a step spans at most a few thousand seconds
-            WRSN_PROF_MARK(sc0_)
-            WRSN_P4_CNT(1, 1) WRSN_P4_MARK(q2_)
-            if (!ev.valid) { WRSN_P4_CNT(3, 1)                                 // charger / condition state only changes when one of them fires
-                int kind_ = -1, idx_ = 0; double bt_ = 0.0; int bp_ = 0; int64_t bs_ = 0; double t2_ = WRSN_INF;
-#define WRSN_CONSIDER(K, I, T_, P_, S_) { const double tt_ = (T_); \
-                    if (kind_ < 0 || key_less(tt_, (P_), (S_), bt_, bp_, bs_)) { if (kind_ >= 0 && bt_ < t2_) t2_ = bt_; kind_ = (K); idx_ = (I); bt_ = tt_; bp_ = (P_); bs_ = (S_); } \
-                    else if (tt_ < t2_) t2_ = tt_; }
-                // four candidates at a time: their fields are fetched back to back (one LDS round trip), then compared
-                const int nth = 2 * M;
-                for (int i0 = 0; i0 < nth; i0 += 4) {
-                    double tt[4]; int64_t sq[4]; int pcs[4], prs[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int i = (i0 + q < nth) ? i0 + q : nth - 1; tt[q] = STH()[i].time; sq[q] = STH()[i].seq; pcs[q] = STH()[i].pc; prs[q] = STH()[i].prio; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (i0 + q < nth && pcs[q] != PC_NONE && pcs[q] != PC_FINISHED) WRSN_CONSIDER(3, i0 + q, tt[q], prs[q], sq[q])
-                }
-                for (int j0 = 1; j0 <= L; j0 += 4) {
-                    double tt[4]; int64_t sq[4]; int pd[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const int j = (j0 + q <= L) ? j0 + q : L; tt[q] = SCT()[j]; sq[q] = SCS()[j]; pd[q] = SCP()[j]; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (j0 + q <= L && pd[q]) WRSN_CONSIDER(4, j0 + q, tt[q], WRSN_NORMAL, sq[q])
-                }
-#undef WRSN_CONSIDER
- WRSN_P4_MARK(q3_) WRSN_P4_SPAN(2, q2_, q3_)
-                ev.kind = kind_; ev.idx = idx_; ev.time = bt_; ev.prio = bp_; ev.seq = bs_; ev.t2 = t2_; ev.valid = 1; ev.uf = -1;
-            }
+    // lane 0: one decision of the event machine on the cached next event.  Returns -1 (go on: the event fired, or the cache is
+    // spent) or the request for the wave.
+    WDEV int scalar_iter(EvCache& ev, const int L, int* pend_out, bool use_limit, double limit, int* arg, double* t_lim_out, int* flags_out) {
             WRSN_P4_MARK(q4_)
-            
             const int kind = ev.kind, idx = ev.idx, bp = ev.prio; const double bt = ev.time; const int64_t bs = ev.seq;
             const bool have_ev = kind >= 0;
             // next grid item (wave-uniform registers; lane 0 holds the same copy)
@@ -1769,12 +1796,10 @@ struct Sim {
             if (use_limit && limit < t_lim) t_lim = limit;
             if (have_grid && (gt < t_lim || (have_ev && gt == bt)) && ev.uf < 0) {
                 // the reward entry list is only needed by a grid service: (re)build it lazily
- WRSN_P4_MARK(q5_) WRSN_P4_CNT(5, 1)
-                WRSN_PROF_MARK(uf0_)
+                WRSN_P4_MARK(q5_) WRSN_P4_CNT(5, 1)
                 ev.uf = ur_flags();
                 if (ev.uf & 1) ur_build(); else SURN()[0] = 0;
                 WRSN_P4_MARK(q6_) WRSN_P4_SPAN(4, q5_, q6_)
-                
                 WRSN_PROF_EV(21, 1) WRSN_PROF_EV(23, SURN()[0])
             }
             // items AT the event's instant that were scheduled before it precede it as well (same time, same NORMAL priority,
@@ -1799,13 +1824,11 @@ struct Sim {
                 *pend_out = REQ_GRID; return REQ_GRID;            // tie at one instant: exactly one grid item goes first
             }
             now = bt; ev.fired++; ev.valid = 0;
- WRSN_P4_MARK(q10_) WRSN_P4_SPAN(10, q4_, q10_)
+            WRSN_P4_MARK(q10_) WRSN_P4_SPAN(10, q4_, q10_)
             if (kind == 3) {
-                WRSN_PROF_MARK(tf0_)
                 WRSN_P4_MARK(q11_) WRSN_P4_CNT(7, 1)
                 int r = thread_fire(idx);
                 WRSN_P4_MARK(q12_) WRSN_P4_SPAN(6, q11_, q12_)
-                
                 if (r) { *arg = (r == REQ_CONN) ? STH()[idx].agent : idx; *pend_out = r; return r; }
                 // the same process usually owns the next event too (its hops at one instant, or its next timeout is
                 // the earliest): no rescan when nothing else can come first
@@ -1822,9 +1845,7 @@ struct Sim {
                 if (idx == L) return REQ_STOP;               // StopSimulation
                 cond_trigger(idx + 1);
             }
-        }
-        err = -6;
-        return REQ_STOP;
+            return -1;
     }
 
     // drive the environment until the run stops: lane 0 fires charger events, the wave runs the grid and the O(N) services
@@ -1841,12 +1862,12 @@ struct Sim {
         for (long guard = 0; guard < 8000000L; ++guard) {
             WRSN_P4_MARK(r0_)
             { WRSN_PROF_T0
-            if (lane == 0) {
+            {
                 int arg = 0, fl = 0; double tl = 0.0;
                 WRSN_P4_MARK(r1_)
-                int req = scalar_run(svc, use_limit, limit, &arg, &tl, &fl);
+                const int req = scalar_run(svc, use_limit, limit, &arg, &tl, &fl);     // every lane; lane 0 holds the details
                 WRSN_P4_MARK(r2_) WRSN_P4_SPAN(0, r1_, r2_)
-                SREQ()[0] = req; SREQ()[1] = arg; SREQ()[3] = fl; SREQD()[0] = tl; SREQD()[1] = now; ((int64_t*)SREQD())[2] = seq;
+                if (lane == 0) { SREQ()[0] = req; SREQ()[1] = arg; SREQ()[3] = fl; SREQD()[0] = tl; SREQD()[1] = now; ((int64_t*)SREQD())[2] = seq; }
             }
             __syncthreads();
             WRSN_PROF_ADD(0) WRSN_PROF_CNT(12, 1) }
