@@ -877,40 +877,46 @@ struct Sim {
         }
     }
 
+    // May a node run dry in the second that starts now?  (Node state at k+0.5 is the state at the start of the second.)  When not:
+    // how many further seconds are safe without looking (safe_ticks); when yes: who (uns_cnt / uns_node).
+    WDEV bool second_is_safe(const double (&rrh)[NPL]) {
+        unsigned trig = 0; double mn = 1e30;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            if ((am >> j) & 1u) {
+                double rr = rrh[j];
+                double a = E[j] - d1[j];
+                double b = fmin(a + rr, cap) - d2[j];
+                // Energy only falls between two half-charges, and an operation fails / kills exactly when the energy
+                // after it is <= thr: with the routing cache valid the second is uneventful iff both segment ends
+                // stay above thr (teps: far above the rounding of the closed form, far below any operation).  Idle
+                // nodes never trigger.
+                if ((d1[j] > 0.0 && a - thr <= teps) || (d2[j] > 0.0 && b - thr <= teps)) trig |= 1u << j;
+                double ds = d1[j] + d2[j];
+                if (ds > 0.0) mn = fmin(mn, (E[j] - thr - opmax) / ds);
+            }
+        }
+        const bool fast = !wv_any(trig != 0);
+        if (!fast) {                                         // who: the exact second starts from the critical source when it is one node
+            uns_cnt = 0; uns_node = -1;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const unsigned long long mk = __ballot((trig >> j) & 1u);
+                uns_cnt += __popcll(mk);
+                if (mk && uns_node < 0) uns_node = j * 64 + __popcll((mk & (~mk + 1ull)) - 1ull);
+            }
+        } else { double m = wv_min(mn); safe_ticks = (m > 4.0) ? (int)fmin(m - 3.0, 1.0e6) : 0; }
+        return fast;
+    }
+
     // -------------------------------------------------------------- k+0.5: Node.operate first half for all nodes (Node.py:57-62)
     WDEV void node_half(const double (&rrh)[NPL], const bool any_rr) {
         if (cache_dirty) { rebuild_cache(); if (!HEAVY) return; }
         bool fast = true;
         if (safe_ticks > 0) { safe_ticks--; }
         else {
-            unsigned trig = 0; double mn = 1e30;
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                if ((am >> j) & 1u) {
-                    double rr = rrh[j];
-                    double a = E[j] - d1[j];
-                    double b = fmin(a + rr, cap) - d2[j];
-                    // Energy only falls between two half-charges, and an operation fails / kills exactly when the energy
-                    // after it is <= thr: with the routing cache valid the second is uneventful iff both segment ends
-                    // stay above thr (teps: far above the rounding of the closed form, far below any operation).  Idle
-                    // nodes never trigger.
-                    if ((d1[j] > 0.0 && a - thr <= teps) || (d2[j] > 0.0 && b - thr <= teps)) trig |= 1u << j;
-                    double ds = d1[j] + d2[j];
-                    if (ds > 0.0) mn = fmin(mn, (E[j] - thr - opmax) / ds);
-                }
-            }
-            fast = !wv_any(trig != 0);
+            fast = second_is_safe(rrh);
             if (!HEAVY && !fast) { need_heavy = 1; return; }  // nothing was touched: the full variant takes this item again
-            if (!fast) {                                     // who: the exact second starts from the critical source when it is one node
-                uns_cnt = 0; uns_node = -1;
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) {
-                    const unsigned long long mk = __ballot((trig >> j) & 1u);
-                    uns_cnt += __popcll(mk);
-                    if (mk && uns_node < 0) uns_node = j * 64 + __popcll((mk & (~mk + 1ull)) - 1ull);
-                }
-            }
-            if (fast) { double m = wv_min(mn); safe_ticks = (m > 4.0) ? (int)fmin(m - 3.0, 1.0e6) : 0; }
         }
         if (fast) {
             if (any_rr) {
@@ -930,21 +936,25 @@ struct Sim {
 #pragma unroll
             for (int j = 0; j < NPL; ++j) if ((am >> j) & 1u) E[j] = fmin(E[j] + rrh[j], cap);
         }
-        if (irreg > 0) {
-            const int len = ring_len, head = ring_head;
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                if ((am >> j) & 1u) {
-                    int i = j * 64 + lane;
-                    double lg = log_pending ? LOGBUF()[i] : (d1[j] + d2[j]);
-                    if (len < WRSN_RING) { RING()[(size_t)len * NP + i] = lg; CS[j] = (CS[j] * len + lg) / (len + 1); }
-                    else { double old = RING()[(size_t)head * NP + i]; CS[j] = (CS[j] * len - old + lg) / len; RING()[(size_t)head * NP + i] = lg; }
-                }
-            }
-            if (len < WRSN_RING) ring_len = len + 1; else ring_head = (head + 1) % WRSN_RING;
-            irreg--; dirty |= 4;
-        }
+        if (irreg > 0) window_update();
         log_pending = 0; n_ticks++;
+    }
+
+    // the sliding consumption window of Node.operate's second half (Node.py:71-77) while it is not uniform yet: the ten seconds
+    // after a routing change or a packet-exact second
+    WDEV void window_update() {
+        const int len = ring_len, head = ring_head;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            if ((am >> j) & 1u) {
+                int i = j * 64 + lane;
+                double lg = log_pending ? LOGBUF()[i] : (d1[j] + d2[j]);
+                if (len < WRSN_RING) { RING()[(size_t)len * NP + i] = lg; CS[j] = (CS[j] * len + lg) / (len + 1); }
+                else { double old = RING()[(size_t)head * NP + i]; CS[j] = (CS[j] * len - old + lg) / len; RING()[(size_t)head * NP + i] = lg; }
+            }
+        }
+        if (len < WRSN_RING) ring_len = len + 1; else ring_head = (head + 1) % WRSN_RING;
+        irreg--; dirty |= 4;
     }
 
     // alpha / (dist(node, charger) + beta)^2 (Node.py:137, WRSN.py:122) of connected node k of charger m at the charger's
@@ -1300,16 +1310,24 @@ struct Sim {
             const double kk = floor(bt);
             // ---- canonical start of a second (setLevels@k+0.1 is a no-op, nodes@k+0.5, reward/alive-check/nodes@k+1.0) on
             //      the steady path: nobody can run dry, the consumption window is uniform, the routing cache is valid
-            if (!one && irreg == 0 && !cache_dirty && !log_pending && safe_ticks > 0 && !levels_dirty && node_phase == 0 &&
+            // (while the consumption window is still filling after a routing change -- irreg > 0 -- the same holds for ONE second at a
+            //  time: its five items run as one pass with the window update of Node.py:71-77 at the end, instead of five loop turns)
+            // (a second in which the safe horizon has run out -- safe_ticks == 0, a node is within a few seconds of its threshold -- is
+            //  looked at first: when nobody runs dry in it, it takes the same single pass)
+            const bool irr = irreg > 0;
+            bool guarded = false;
+            if (!one && !cache_dirty && !log_pending && !levels_dirty && node_phase == 0 &&
                 (net_active ? (k == 0 && net_phase == 0) : (k == 2)) && ur_time == kk + 1.0) {
                 // whole seconds that fit before the next charger event / max_time and stay inside the safe horizon
                 double jf = floor(fmin(t_limit, kk + 1.0e6) - kk);
                 if (kk + jf >= t_limit) jf -= 1.0;
                 if (net_active) { double jm = floor(fmin(max_time, kk + 1.0e6) - kk); if (kk + jm >= max_time) jm -= 1.0; jf = fmin(jf, jm); }
                 int j = (int)fmin(jf, (double)safe_ticks);
-                if (budget > 0 && j > budget - work) j = (budget - work > 1) ? budget - work : 1;
+                if (safe_ticks == 0 && jf >= 1.0) { work += 4; if (second_is_safe(rrh)) { guarded = true; j = 1; } }
+                if (budget > 0 && j > 1 && j > budget - work) j = (budget - work > 1) ? budget - work : 1;
+                if ((irr || guarded) && j > 1) j = 1;
                 if (j >= 1) {
-                    if (!any_rr && !ur_flag) {
+                    if (!any_rr && !ur_flag && !irr && !guarded) {
                         // nothing but the constant per-second drain: closed form
                         const double dj = (double)j;
 #pragma unroll
@@ -1320,7 +1338,7 @@ struct Sim {
                     ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
                     if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
                     else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; }
-                    now = ke; n_ticks += j; safe_ticks -= j;
+                    now = ke; n_ticks += j; if (!guarded) safe_ticks -= j;
                     if (!fused) continue;
                 }
             }
@@ -1383,6 +1401,7 @@ struct Sim {
                 }
             }
             WRSN_PROF_MARK(ps1_) WRSN_PROF_SPAN(19, ps0_, ps1_)
+            if (fused && irr) { window_update(); work += 8; }
             if (fused) continue;
             if (one || deaths_flag) break;
         }

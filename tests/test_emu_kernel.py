@@ -166,6 +166,47 @@ def test_emulated_step_budget_returns_the_same_requests(name):
     assert n_susp > 0
 
 
+def test_emulated_step_budget_equals_blocking_on_a_200_node_network_with_guarded_seconds():
+    """A synthetic 200-node environment whose run passes through seconds that are looked at one by one (a node within a few
+    seconds of its threshold: safe horizon 0) while the launch budget runs out: the budgeted requests equal the blocking
+    ones.  (Regression: an exhausted budget once turned "no second may be skipped" into "skip one".)"""
+    import torch
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    K, e = 12, 92
+    acts = torch.rand((K, 96, 3), generator=torch.Generator().manual_seed(3), dtype=torch.float64).numpy()[:, e]
+    sc = [synth_scenario(500 + e, 200, 200)]
+
+    def run(budget):
+        ev = _emu(sc, DEFAULT_MC_SPEC, 3)
+        if budget:
+            ev.h.set_step_budget(budget)
+        ev.reset(with_obs=False)
+        hist, k, busy, cur = [], 0, False, ev.agent_id.copy()
+        for _ in range(4000):
+            if k >= K and not busy:
+                break
+            ev.step(cur, acts[min(k, K - 1)][None], with_obs=False)
+            if int(ev.status[0]) == 4:
+                k += 0 if busy else 1
+                busy = True
+                continue
+            k += 0 if busy else 1
+            busy = False
+            hist.append((int(ev.agent_id[0]), float(ev.now[0]), float(ev.reward[0]), int(ev.terminal[0])))
+            if ev.terminal[0] or ev.agent_id[0] < 0:
+                break
+            cur = ev.agent_id.copy()
+        return hist, ev.nodes()["energy"][0].copy()
+
+    h0, e0 = run(0)
+    h1, e1 = run(400)
+    assert len(h0) == len(h1) and len(h0) >= 4
+    for q0, q1 in zip(h0, h1):
+        assert q0[0] == q1[0] and q0[1] == q1[1] and q0[3] == q1[3], (q0, q1)
+        assert abs(q0[2] - q1[2]) <= 1e-7 * max(1.0, abs(q0[2])), (q0, q1)
+    assert np.abs(e0 - e1).max() <= 1e-8 * np.abs(e0).max()
+
+
 def test_emulated_rollout_table_matches_host_accumulation():
     """wrsn_rollout_table: returns per charger / finished episodes / lifetimes / completed steps accumulated by the step
     kernel equal what a host loop over the requests accumulates (RolloutStats layout)."""
