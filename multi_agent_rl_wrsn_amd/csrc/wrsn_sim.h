@@ -2558,10 +2558,11 @@ struct WrsnFalse { static constexpr bool value = false; };
 // map_1[i][j] = sum over alive nodes of w_n g(x_i - x_n; hX) g(y_j - y_n; hY) is a rank-N sum of separable Gaussians,
 // i.e. the GEMM (w .* Gx)^T Gy with M = N = G (100) and K = #nodes: it runs on the matrix cores with the exact-f32
 // v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain over the nodes).  One 256-thread workgroup per environment: wave w
-// owns the 32-row band w of the (padded 128 x 128) map = 4 accumulator tiles; node chunks are expanded into LDS rows
+// owns the 32-row band w of the (padded 128 x 128) map = 4 accumulator tiles; node chunks are expanded in registers into
 // A[k][i] = w_k g(x_i - x_k), B[k][j] = g(y_j - y_k).  Maps 2-4 are at most M rank-1 terms and stay on the VALU.
 #define WRSN_OBS_CH 8
 #define WRSN_OBS_LD 128
+#define WRSN_OBS_AG_FLOATS ((WRSN_MAX_MC * (int)sizeof(WrsnAgent) + 15) / 16 * 4)   // LDS floats of the staged chargers
 #ifndef WRSN_V16F_DEFINED
 typedef float wrsn_v16f __attribute__((ext_vector_type(16)));
 #endif
@@ -2589,7 +2590,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     float* pyt = pxb + 3 * NS;                             // [4][NS]  y - (32 t + 16) / G
     float* wf = pyt + 4 * NS;                              // [NS] weight as float32 (0: dead / padding)
     float* bbox = wf + NS;                                 // [NP / CH + 2][4] x / y range of the weighted nodes of a chunk
-    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // three wave-private (A [CH][32], B [CH][128]) buffer pairs, then the term rows
+    float* A = bbox + 4 * (NP / WRSN_OBS_CH + 2);          // the chargers of the environment (WRSN_OBS_AG_FLOATS), then the term rows
     const double fx0 = ec->frame[0], fy0 = ec->frame[2];
     const double W = ec->frame[1] - fx0, H = ec->frame[3] - fy0;
     const double unit = 1.0 / G;
@@ -2612,8 +2613,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
 #else
 #define WRSN_OBS_STAMP(k)
 #endif
-    // the chargers of the environment go to LDS in one coalesced round trip (the term rows below read a dozen of their fields);
-    // they sit in the first wave buffer, which is not in use before the second barrier
+    // the chargers of the environment go to LDS in one coalesced round trip (the term rows below read a dozen of their fields)
     WrsnAgent* sag = (WrsnAgent*)A;
     {
         const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)sag;
@@ -2662,7 +2662,7 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     // maps 2..4: own charger (map 2), others charging (map 3), others moving (map 4): at most M rank-1 terms.  Their term rows
     // gx[t][G] (already scaled) and gy[t][G] go to LDS rows of their own; wave 3 (the "store wave", below) turns them into the
     // three maps while waves 0..2 are busy with the matrix cores.
-    float* tx = A + 3 * (WRSN_OBS_CH * (32 + WRSN_OBS_LD)); float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
+    float* tx = A + WRSN_OBS_AG_FLOATS; float* ty = tx + WRSN_MAX_MC * WRSN_OBS_LD; int* tmap = (int*)(ty + WRSN_MAX_MC * WRSN_OBS_LD);
     int* row_ctr = tmap + WRSN_MAX_MC;                     // next pair of rows of maps 2..4 to be written (claimed with an LDS atomic)
     {
     const WrsnAgent* ag = sag;
@@ -2693,14 +2693,12 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
     __syncthreads();
     WRSN_OBS_STAMP(1)
     WRSN_OBS_STAMP(2)
-    // Map 1: every wave works on its own 32-row band with LDS buffers of its own and walks only the chunks (eight nodes
-    // each, Morton order: neighbours in the plane) with a weighted node that reaches a row of the band -- a Gaussian
-    // further than 6.5 bandwidths away contributes less than 7e-10 of its peak and is skipped.  Per chunk the wave expands
-    // its 32 x-columns and the 128 y-columns of the eight nodes (20 elements per lane: coordinate difference in float64,
-    // v_exp_f32) and issues the 16 MFMAs.  No workgroup barrier: a band's time follows its own work, and the waves of the
-    // other resident blocks fill the matrix-core and VALU gaps.
-    float* Aw = A + wave * (WRSN_OBS_CH * (32 + WRSN_OBS_LD));   // [CH][32]   weight * g(x_row - x_n) for the band's rows
-    float* Bw = Aw + WRSN_OBS_CH * 32;                           // [CH][128]  g(y - y_n)
+    // Map 1: every wave works on its own 32-row band and walks only the chunks (eight nodes each, Morton order: neighbours
+    // in the plane) with a weighted node that reaches a row of the band -- a Gaussian further than 6.5 bandwidths away
+    // contributes less than 7e-10 of its peak and is skipped.  Per chunk a lane expands the Gaussians of its row and of its
+    // column in every tile in reach for four of the eight nodes (20 v_exp_f32, float32 offsets from the band / tile centre)
+    // and the wave issues up to 16 MFMAs.  No barrier of any kind: a band's time follows its own work, and the waves of
+    // the other resident blocks fill the matrix-core and VALU gaps.
     const float kx = inv2hx * 1.44269504f, ky = inv2hy * 1.44269504f;       // exp(t) = 2^(t log2 e)
     const float off = (float)((l31 - 15.5) * unit);        // this lane's row (A) / column (B) relative to the band / tile centre
     const float rx = 6.5f * (float)hX, ry = 6.5f * (float)hY;
@@ -2719,13 +2717,15 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
             for (int t = 0; t < 4; ++t) tmask |= (int)(cy_lo <= (float)((32 * t + 31.5) * unit) && cy_hi >= (float)((32 * t + 0.5) * unit)) << t;
             tmask = __builtin_amdgcn_readfirstlane(tmask);
             const float* wn = wf + c * WRSN_OBS_CH;
-#ifndef WRSN_OBS_NO_FILL
-            // A [8 nodes][32 rows] and, per tile in reach, B [8 nodes][32 columns]: a lane expands node (l >> 5) + 2 m at row / column l & 31
+            // Operand layout of v_mfma_f32_32x32x2_f32: lane l feeds element [l & 31][k = l >> 5] of both operands.  With k = node
+            // (l >> 5) + 2 m of the chunk, a lane therefore consumes exactly the Gaussians of ITS row / column l & 31: they are expanded
+            // straight into registers (20 v_exp_f32 per lane and chunk) -- no LDS staging, no barrier between expansion and MFMA.
+            float av[WRSN_OBS_CH / 2], bv[4][WRSN_OBS_CH / 2];
 #pragma unroll
             for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {
                 const int n = half + 2 * m;
                 const float df = off - pxw[c * WRSN_OBS_CH + n];
-                Aw[n * 32 + l31] = __builtin_amdgcn_exp2f(df * df * kx) * wn[n];
+                av[m] = __builtin_amdgcn_exp2f(df * df * kx) * wn[n];          // weight * g(x_row - x_n)
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -2733,27 +2733,22 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
                     const float* pyw = pyt + t * NS + c * WRSN_OBS_CH;
 #pragma unroll
                     for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {
-                        const int n = half + 2 * m;
-                        const float df = off - pyw[n];
-                        Bw[n * WRSN_OBS_LD + 32 * t + l31] = __builtin_amdgcn_exp2f(df * df * ky);
+                        const float df = off - pyw[half + 2 * m];
+                        bv[t][m] = __builtin_amdgcn_exp2f(df * df * ky);        // g(y_col - y_n)
                     }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < WRSN_OBS_CH / 2; ++m) bv[t][m] = 0.f;
                 }
             }
-#endif
-            __builtin_amdgcn_wave_barrier();
-#ifndef WRSN_OBS_NO_MFMA
             // D[m][n] = sum_k Ay[m][k] Bx[k][n] with m = map column inside tile t, n = band row: the accumulator registers of a
             // lane then run along the map's COLUMNS (row = lane & 31), which lets the store below write 16 bytes at a time
 #pragma unroll
-            for (int k2 = 0; k2 < WRSN_OBS_CH; k2 += 2) {
-                // first operand: lane -> [m = l & 31][k = l >> 5];  second operand: lane -> [k = l >> 5][n = l & 31]
-                const float bx = Aw[(k2 + half) * 32 + l31];
+            for (int m = 0; m < WRSN_OBS_CH / 2; ++m) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if ((tmask >> t) & 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Bw[(k2 + half) * WRSN_OBS_LD + 32 * t + l31], bx, acc[t], 0, 0, 0);
+                    if ((tmask >> t) & 1) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t][m], av[m], acc[t], 0, 0, 0);
             }
-#endif
-            __builtin_amdgcn_wave_barrier();                   // the next chunk overwrites the buffers
         }
     }
     WRSN_OBS_STAMP(3)
@@ -2864,4 +2859,4 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
 #endif
 }
 
-static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * 8 * 4 + 16 * (NP / WRSN_OBS_CH + 2) + 3 * WRSN_OBS_CH * (32 + WRSN_OBS_LD) * 4 + 2 * WRSN_MAX_MC * WRSN_OBS_LD * 4 + 64; }
+static inline int wrsn_obs_lds_bytes(int G, int NP) { (void)G; return (NP + 2 * WRSN_OBS_CH) * 8 * 4 + 16 * (NP / WRSN_OBS_CH + 2) + WRSN_OBS_AG_FLOATS * 4 + 2 * WRSN_MAX_MC * WRSN_OBS_LD * 4 + 64; }
