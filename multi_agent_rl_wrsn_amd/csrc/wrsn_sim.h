@@ -2620,7 +2620,10 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
         for (int w = tid; w < M * (int)(sizeof(WrsnAgent) / 8); w += 256) la[w] = ga[w];
     }
     if (!keep1) {   // node parameters once: w_n = (CS / (alpha/beta^2)) / ((E - thr) / (cap - thr))   (WRSN.py:146)
+        // one float64 division per node: w = CS span / (a_b2 (E - thr)); the frame scaling multiplies by the reciprocals of W and H
+        // (the results are rounded to float32 right below)
         const double a_b2 = ec->alpha / (ec->beta * ec->beta), thr = ec->threshold, span = ec->capacity - ec->threshold;
+        const double invW = 1.0 / W, invH = 1.0 / H;
         for (int n = tid; n < NP; n += 256) {
             double w = 0.0, cx = 0.0, cy = 0.0;
             const int src = (n < N) ? d.xorder[nb + n] : 0;  // position n of the Morton order (static, built with the topology)
@@ -2628,8 +2631,8 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
             const int lsw = d.live.ls[nb + src];
             const double px = d.node_x[nb + src], py = d.node_y[nb + src], en = d.live.E[nb + src], csv = d.live.CS[nb + src];
             if (n < N && (lsw & 1)) {
-                cx = (px - fx0) / W; cy = (py - fy0) / H;
-                w = (csv / a_b2) / ((en - thr) / span);
+                cx = (px - fx0) * invW; cy = (py - fy0) * invH;
+                w = (csv * span) / (a_b2 * (en - thr));
             }
 #pragma unroll
             for (int w = 0; w < 3; ++w) pxb[w * NS + n] = (float)(cx - (32 * w + 16) * unit);
@@ -2679,11 +2682,12 @@ __global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32
             if (ag[o].type_charging) { mp = 2; val = ag[o].cur[2] / ec->charging_time_max; }          // map_3: others not "moving"
             else { mp = 3; val = (dist2(ag[o].loc[0], ag[o].loc[1], ag[o].cur[0], ag[aid].cur[1]) / ec->velocity) / ec->moving_time_max; }   // map_4, mixed index as in WRSN.py:184
         }
+        const double ihx = -0.5 / (hx * hx), ihy = -0.5 / (hy * hy);      // block-uniform
         for (int idx = tid; idx < 2 * G; idx += 256) {
             const bool isx = idx < G; const int c = isx ? idx : idx - G;
             const double cen = unit / 2 + c * unit;
-            const double df = cen - (isx ? cxo : cyo); const double h = isx ? hx : hy;
-            const float g = __expf((float)(df * df / (-2.0 * h * h)));
+            const double df = cen - (isx ? cxo : cyo);
+            const float g = __expf((float)(df * df * (isx ? ihx : ihy)));
             if (isx) tx[o * WRSN_OBS_LD + c] = g * (float)val; else ty[o * WRSN_OBS_LD + c] = g;
         }
         if (tid == 0) tmap[o] = mp;

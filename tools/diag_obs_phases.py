@@ -10,6 +10,7 @@ env = VecWRSN([synth_scenario(e, 200, 200) for e in range(B)], None, 3, auto_res
 r = env.reset(); g = torch.Generator(device="cuda").manual_seed(0)
 for _ in range(4): r = env.step(r["agent_id"], torch.rand((B, 3), generator=g, device="cuda", dtype=torch.float64))
 ids = r["agent_id"].clamp(min=0).to(torch.int32)
+if len(sys.argv) > 1 and sys.argv[1] == "full": env._h.set_obs_reuse(False)      # every render draws map 1 (default: map 1 of the row is reused)
 for _ in range(3): env.render_state(ids, out=env.state)
 torch.cuda.synchronize()
 a = np.zeros((B * 25,), dtype=np.int64)
