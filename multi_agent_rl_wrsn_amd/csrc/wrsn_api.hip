@@ -58,7 +58,8 @@ struct wrsn_handle {
     int npl;
     int scenario_set;
     int lds_env, lds_obs;
-    int slots;                 // wave slots of the device for the step kernel (CUs x 8): launch-order dependent budgets
+    int slots;                 // wave slots of the device for the step kernel (CUs x resident waves per CU): launch-order dependent budgets
+    int waves_per_cu;          // what the occupancy query said for this handle's step kernel (diagnostic)
     long long epoch;           // launch counter of budgeted wrsn_step calls (epoch % 3 selects the in-flight list)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
@@ -236,6 +237,20 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         int RPG = (d.G + RG - 1) / RG; if (RPG > WRSN_OBS_MAXROWS) { delete h; return fail(WRSN_ERR_ARG, "map_size too large for the observation tile"); }
     }
     h->lds_env = wrsn_lds_bytes(d.NP, d.M);
+    {   // wave slots of the step kernel on this device (registers and LDS decide: 8 per CU up to 256 nodes, 3 at 1 024 nodes x 8 chargers):
+        // the budget taper of a launch starts behind the blocks that are resident from the first moment
+        int per_cu = 0; hipError_t oe = hipErrorUnknown;
+        const int lds_b = h->lds_env + h->lds_pad;
+        switch (h->npl) {
+        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<1, true>, 64, (size_t)lds_b); break;
+        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<2, true>, 64, (size_t)lds_b); break;
+        case 4: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<4, true>, 64, (size_t)lds_b); break;
+        case 8: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<8, true>, 64, (size_t)lds_b); break;
+        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<16, true>, 64, (size_t)lds_b); break;
+        }
+        if (oe == hipSuccess && per_cu >= 1 && per_cu <= 8) h->slots = (h->slots / 8) * per_cu;
+        h->waves_per_cu = (oe == hipSuccess) ? per_cu : 0;
+    }
     h->lds_obs = wrsn_obs_lds_bytes(d.G, d.NP);
     const size_t B = d.B, NP = d.NP;
     int rc = 0;

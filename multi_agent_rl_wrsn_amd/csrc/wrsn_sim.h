@@ -20,7 +20,8 @@
 #include "wrsn_types.h"
 
 #define WDEV __device__ __forceinline__
-#define WRSN_CHG_MAX 8                    // nodes under charge handled by the time-parallel steady batch
+#define WRSN_CHG_MAX(NP_) ((NP_) > 512 ? 6 : 8)   // nodes under charge handled by the time-parallel steady batch (six above 512 nodes: three
+                                           // environments of 1 024 nodes x 8 chargers then fit the 160 KB of LDS of a CU instead of two)
 // Diagnostic build only (-DWRSN_PROFILE, tools/build_profile.sh): per-phase cycle totals per environment.  Stamps go
 // to a buffer of their own (WrsnDev.counters) and no output is computed from them; the product build has none.
 #if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
@@ -259,6 +260,7 @@ struct Sim {
     WRSN_PROF_DECL
 
     struct alignas(16) U4 { uint32_t x, y, z, w; };
+    static constexpr int kChgMax = WRSN_CHG_MAX(64 * NPL);
     // lane-0 bookkeeping of the scalar event processor lives in LDS, not in registers
     struct Scalar { double ev_time, ev2_time; int64_t ev_seq, n_events; int32_t L, pend, pend_idx, ev_valid, ev_kind, ev_idx, ev_prio, ev_uf; };
     static_assert(sizeof(Scalar) == WRSN_LDS_SCALAR_BYTES, "wrsn_lds_bytes must match");
@@ -292,8 +294,8 @@ struct Sim {
     // time-parallel steady batch: float CS per node, records / per-second table of the (few) nodes being charged
     WDEV float* SCSF() const { return (float*)(smem_ + 4 * NP); }
     WDEV double* SCHGREC() const { return smem_ + 4 * NP + NP / 2; }                       // [CHG_MAX][8]: E, d1, d2, rr, node, E_final, CS
-    WDEV double* SCHGTAB() const { return SCHGREC() + 8 * WRSN_CHG_MAX; }                 // [CHG_MAX][64] energy at the reward instant of second s
-    WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(SCHGTAB() + 64 * WRSN_CHG_MAX); }
+    WDEV double* SCHGTAB() const { return SCHGREC() + 8 * kChgMax; }                 // [CHG_MAX][64] energy at the reward instant of second s
+    WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(SCHGTAB() + 64 * kChgMax); }
     WDEV WrsnThread* STH() const { return (WrsnThread*)(SAG() + M); }
     WDEV double* SCT() const { return (double*)(STH() + 2 * M); }
     WDEV int64_t* SCS() const { return (int64_t*)(SCT() + (M + 1)); }
@@ -1020,7 +1022,7 @@ struct Sim {
     // per second by one lane each and are added after the main loops (they are staged as "priority 0" nodes, whose
     // term is taken out again).  The reward priorities of every second (update_reward, WRSN.py:100-127) need no
     // cross-lane reduction this way; the contributions of the connected nodes are summed over the seconds with one
-    // wave reduction per charger.  Returns false (nothing done) when more than WRSN_CHG_MAX nodes are being charged.
+    // wave reduction per charger.  Returns false (nothing done) when more than kChgMax nodes are being charged.
     struct alignas(16) D2 { double x, y; };
     struct alignas(8) F2 { float x, y; };
     WDEV bool steady_batch(int nb, const double (&rrh)[NPL], bool any_rr) { WRSN_PROF_T0
@@ -1037,11 +1039,11 @@ struct Sim {
                 cpos[j] = nchg + __popcll(mk & ((1ull << lane) - 1ull));
                 if (c) {
                     cm |= 1u << j;
-                    if (cpos[j] < WRSN_CHG_MAX) { double* r = rec + 8 * cpos[j]; r[0] = E[j]; r[1] = d1[j]; r[2] = d2[j]; r[3] = rrh[j]; r[4] = (double)(j * 64 + lane); r[6] = CS[j]; }
+                    if (cpos[j] < kChgMax) { double* r = rec + 8 * cpos[j]; r[0] = E[j]; r[1] = d1[j]; r[2] = d2[j]; r[3] = rrh[j]; r[4] = (double)(j * 64 + lane); r[6] = CS[j]; }
                 }
                 nchg += __popcll(mk);
             }
-            if (nchg > WRSN_CHG_MAX) return false;
+            if (nchg > kChgMax) return false;
         }
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {

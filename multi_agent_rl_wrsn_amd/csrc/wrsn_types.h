@@ -128,7 +128,8 @@ static inline int wrsn_lds_bytes(int NP, int M) {
     b += 4 * 8 + WRSN_LDS_SCALAR_BYTES + 4 * 4;       // mailbox doubles, scalar bookkeeping, mailbox ints
     b += 3 * (M + 1) * 4 + 4;                         // condition agent / triggered / pending, reward-entry count
     b += 3 * M * WRSN_CONN_CAP * 2;                   // connected-node ids, reward-entry node / charger
-    b += NP * 4 + 8 * 8 * 8 + 8 * 64 * 8;             // steady batch: float CS, charged-node records and table (WRSN_CHG_MAX = 8)
+    const int chg = NP > 512 ? 6 : 8;                 // WRSN_CHG_MAX(NP) of wrsn_sim.h
+    b += NP * 4 + chg * 8 * 8 + chg * 64 * 8;         // steady batch: float CS, charged-node records and table
     b += (int)sizeof(WrsnEnvConst);                   // constants of the environment
     return (b + 31) & ~15;
 }
