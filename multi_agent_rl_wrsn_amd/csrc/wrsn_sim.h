@@ -333,9 +333,9 @@ struct Sim {
     // -------------------------------------------------------------- static graph data of the lane's nodes
     // Neighbour lists are sorted by (distance, id) when the topology is built, so Node.find_receiver (Node.py:92-100:
     // the first strictly nearer candidate in id order) is "the first eligible neighbour".  The eight nearest ids of a
-    // node are packed 16 bit each (0xFFFF = none) next to the send cost of that hop; nodes with more neighbours (or
-    // NPL > 6, where the ids would not fit the register file) walk the sorted CSR lists instead.  A routine that sweeps
-    // the graph loads these once (independent 16-byte loads) and then only touches LDS.
+    // node are packed 16 bit each (0xFFFF = none) next to the send cost of that hop; nodes with more neighbours walk the
+    // sorted CSR lists instead.  A routine that sweeps the graph loads these once (independent 16-byte loads) and then only
+    // touches LDS; with NPL > 6 the ids would not fit the register file and every sweep re-reads the (L2-resident) table.
     static constexpr bool kNbReg = (NPL <= 6);
     struct NbRegs { uint32_t p[kNbReg ? NPL : 1][4]; unsigned ovf, direct; int ncov[NPL]; };
     WDEV void load_neighbors(NbRegs& nb) const {
@@ -345,12 +345,19 @@ struct Sim {
             const int i = j * 64 + lane;
             const int f = NFLAGS()[i];
             nb.direct |= (unsigned)(f & 1) << j; nb.ncov[j] = f >> 8;
+            nb.ovf |= (unsigned)((f >> 1) & 1) << j;
             if (kNbReg) {
-                nb.ovf |= (unsigned)((f >> 1) & 1) << j;
                 const U4 v = NBP()[i];
                 nb.p[kNbReg ? j : 0][0] = v.x; nb.p[kNbReg ? j : 0][1] = v.y; nb.p[kNbReg ? j : 0][2] = v.z; nb.p[kNbReg ? j : 0][3] = v.w;
-            } else nb.ovf |= 1u << j;
+            }
         }
+    }
+    // the packed neighbour words of register slot j: from the registers, or (NPL > 6) one coalesced 16-byte load from the static table.
+    // A sweep fetches them kNbGrp slots at a time so that the loads of a group are in flight together.
+    static constexpr int kNbGrp = kNbReg ? 1 : 4;
+    WDEV U4 nb_words(const NbRegs& nb, int j) const {
+        if (kNbReg) { U4 v; v.x = nb.p[kNbReg ? j : 0][0]; v.y = nb.p[kNbReg ? j : 0][1]; v.z = nb.p[kNbReg ? j : 0][2]; v.w = nb.p[kNbReg ? j : 0][3]; return v; }
+        return NBP()[j * 64 + lane];
     }
     // eight packed ids -> indices (`self` where the slot is empty) and a validity mask
     WDEV static unsigned unpack8(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int self, int (&idx)[8]) {
@@ -382,7 +389,7 @@ struct Sim {
     // one memory round trip), or -1 with the cost in *es (CSR path)
     WDEV int find_receiver(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, bool ovf, int i, int lvl, int* wsel_out, double* es) const {
         int r = -1; *wsel_out = -1; *es = 0.0;
-        if (kNbReg && !ovf) {
+        if (!ovf) {
             int wsel = 0; int idx[8], l2[8];
             const unsigned ok = unpack8(p0, p1, p2, p3, i, idx);
             wrsn_lds_gather8_b32(SLS(), idx, l2);
@@ -530,18 +537,25 @@ struct Sim {
         for (int cur = 1; cur <= N; ++cur) {
             bool ch = false;
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int i = j * 64 + lane;
-                const int ls = SLS()[i];
-                int hit = 0;
-                if (kNbReg && !((nbr.ovf >> j) & 1u)) {
-                    int idx[8], l2[8];
-                    const unsigned ok = unpack8(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], i, idx);
-                    wrsn_lds_gather8_b32(SLS(), idx, l2);
+            for (int j0 = 0; j0 < NPL; j0 += kNbGrp) {
+                U4 pk[kNbGrp];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) hit |= (int)((ok >> k) & 1u) & l2[k] & (int)(((l2[k] >> 1) - 1) == cur);
-                } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { const int l2 = SLS()[nb]; hit |= l2 & (int)(((l2 >> 1) - 1) == cur); })
-                if ((ls & 1) && (ls >> 1) == 0 && (hit & 1)) { SLS()[i] = ((cur + 2) << 1) | 1; ch = true; }   // alive, level == -1
+                for (int q = 0; q < kNbGrp; ++q) pk[q] = nb_words(nbr, j0 + q);
+#pragma unroll
+                for (int q = 0; q < kNbGrp; ++q) {
+                    const int j = j0 + q;
+                    const int i = j * 64 + lane;
+                    const int ls = SLS()[i];
+                    int hit = 0;
+                    if (!((nbr.ovf >> j) & 1u)) {
+                        int idx[8], l2[8];
+                        const unsigned ok = unpack8(pk[q].x, pk[q].y, pk[q].z, pk[q].w, i, idx);
+                        wrsn_lds_gather8_b32(SLS(), idx, l2);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) hit |= (int)((ok >> k) & 1u) & l2[k] & (int)(((l2[k] >> 1) - 1) == cur);
+                    } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { const int l2 = SLS()[nb]; hit |= l2 & (int)(((l2 >> 1) - 1) == cur); })
+                    if ((ls & 1) && (ls >> 1) == 0 && (hit & 1)) { SLS()[i] = ((cur + 2) << 1) | 1; ch = true; }   // alive, level == -1
+                }
             }
             __syncthreads();
             if (!wv_any(ch)) break;
@@ -579,15 +593,22 @@ struct Sim {
         NbRegs nbr; load_neighbors(nbr);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane;
-            int ls = SLS()[i]; int lvl = (ls >> 1) - 1;
-            int r = -1; double e1 = 0.0; int ws = -1;
-            if ((nbr.direct >> j) & 1u) r = -2;
-            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, lvl, &ws, &e1);
-            if (!(ls & 1)) { r = -1; e1 = 0.0; ws = -1; }
-            es[j] = e1; rc[j] = r; wsl[j] = ws;
-            SRCV()[i] = r; c1[i] = 0; c2[i] = 0;
+        for (int j0 = 0; j0 < NPL; j0 += kNbGrp) {
+            U4 pk[kNbGrp];
+#pragma unroll
+            for (int q = 0; q < kNbGrp; ++q) pk[q] = nb_words(nbr, j0 + q);
+#pragma unroll
+            for (int q = 0; q < kNbGrp; ++q) {
+                const int j = j0 + q;
+                int i = j * 64 + lane;
+                int ls = SLS()[i]; int lvl = (ls >> 1) - 1;
+                int r = -1; double e1 = 0.0; int ws = -1;
+                if ((nbr.direct >> j) & 1u) r = -2;
+                else r = find_receiver(pk[q].x, pk[q].y, pk[q].z, pk[q].w, (nbr.ovf >> j) & 1u, i, lvl, &ws, &e1);
+                if (!(ls & 1)) { r = -1; e1 = 0.0; ws = -1; }
+                es[j] = e1; rc[j] = r; wsl[j] = ws;
+                SRCV()[i] = r; c1[i] = 0; c2[i] = 0;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {                      // send costs of all slots: independent loads, one round trip
@@ -640,13 +661,20 @@ struct Sim {
         __syncthreads();
         int rc[NPL], wsl[NPL];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane; int r = -1; double e1 = 0.0; int ws = -1;
-            const int ls = SLS()[i];
-            if ((nbr.direct >> j) & 1u) r = -2;
-            else r = find_receiver(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], (nbr.ovf >> j) & 1u, i, (ls >> 1) - 1, &ws, &e1);
-            if (!(ls & 1)) { r = -1; e1 = 0.0; ws = -1; }
-            es[j] = e1; rc[j] = r; wsl[j] = ws;
+        for (int j0 = 0; j0 < NPL; j0 += kNbGrp) {
+            U4 pk[kNbGrp];
+#pragma unroll
+            for (int q = 0; q < kNbGrp; ++q) pk[q] = nb_words(nbr, j0 + q);
+#pragma unroll
+            for (int q = 0; q < kNbGrp; ++q) {
+                const int j = j0 + q;
+                int i = j * 64 + lane; int r = -1; double e1 = 0.0; int ws = -1;
+                const int ls = SLS()[i];
+                if ((nbr.direct >> j) & 1u) r = -2;
+                else r = find_receiver(pk[q].x, pk[q].y, pk[q].z, pk[q].w, (nbr.ovf >> j) & 1u, i, (ls >> 1) - 1, &ws, &e1);
+                if (!(ls & 1)) { r = -1; e1 = 0.0; ws = -1; }
+                es[j] = e1; rc[j] = r; wsl[j] = ws;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {                      // send costs of all slots: independent loads, one round trip
@@ -1212,18 +1240,25 @@ struct Sim {
         for (int it = 0; it <= N; ++it) {
             bool ch = false;
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int i = j * 64 + lane;
-                double best = -1.0;                         // dead / unreached neighbours hold -1
-                if (kNbReg && !((nbr.ovf >> j) & 1u)) {
-                    int idx[8]; double tn[8];
-                    const unsigned ok = unpack8(nbr.p[kNbReg ? j : 0][0], nbr.p[kNbReg ? j : 0][1], nbr.p[kNbReg ? j : 0][2], nbr.p[kNbReg ? j : 0][3], i, idx);
-                    wrsn_lds_gather8_b64(t, idx, tn);
+            for (int j0 = 0; j0 < NPL; j0 += kNbGrp) {
+                U4 pk[kNbGrp];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) best = fmax(best, ((ok >> k) & 1u) ? tn[k] : -1.0);
-                } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { best = fmax(best, t[nb]); })
-                const double cand = fmin(lt[j], best);
-                if (((nd >> j) & 1u) && cand > tc[j]) { tc[j] = cand; t[i] = cand; ch = true; }
+                for (int q = 0; q < kNbGrp; ++q) pk[q] = nb_words(nbr, j0 + q);
+#pragma unroll
+                for (int q = 0; q < kNbGrp; ++q) {
+                    const int j = j0 + q;
+                    const int i = j * 64 + lane;
+                    double best = -1.0;                     // dead / unreached neighbours hold -1
+                    if (!((nbr.ovf >> j) & 1u)) {
+                        int idx[8]; double tn[8];
+                        const unsigned ok = unpack8(pk[q].x, pk[q].y, pk[q].z, pk[q].w, i, idx);
+                        wrsn_lds_gather8_b64(t, idx, tn);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) best = fmax(best, ((ok >> k) & 1u) ? tn[k] : -1.0);
+                    } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { best = fmax(best, t[nb]); })
+                    const double cand = fmin(lt[j], best);
+                    if (((nd >> j) & 1u) && cand > tc[j]) { tc[j] = cand; t[i] = cand; ch = true; }
+                }
             }
             __syncthreads();
             if (!wv_any(ch)) break;
