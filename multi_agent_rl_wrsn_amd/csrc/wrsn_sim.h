@@ -523,6 +523,11 @@ struct Sim {
             __syncthreads();
         } else {
         NbRegs nbr; load_neighbors(nbr);
+        // the packed neighbour words of all nodes go to the scratch array (16 bytes per node, idle during this service): every BFS
+        // level then reads them from LDS instead of from the table in global memory
+        U4* snb = (U4*)SU();
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) snb[j * 64 + lane] = NBP()[j * 64 + lane];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
@@ -540,7 +545,7 @@ struct Sim {
             for (int j0 = 0; j0 < NPL; j0 += kNbGrp) {
                 U4 pk[kNbGrp];
 #pragma unroll
-                for (int q = 0; q < kNbGrp; ++q) pk[q] = nb_words(nbr, j0 + q);
+                for (int q = 0; q < kNbGrp; ++q) pk[q] = snb[(j0 + q) * 64 + lane];
 #pragma unroll
                 for (int q = 0; q < kNbGrp; ++q) {
                     const int j = j0 + q;

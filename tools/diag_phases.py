@@ -15,8 +15,9 @@ def prof(env):
     return a[:env.num_env * 24].reshape(env.num_env, 24).copy(), a[env.num_env * 24:].copy()
 if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    scs = [synth_scenario(e, 200, 200) for e in range(B)]
-    env = VecWRSN(scs, None, 3, auto_reset=True, render=False)
+    NN = int(os.environ.get("WRSN_N", "200")); MM = int(os.environ.get("WRSN_M", "3"))
+    scs = [synth_scenario(e, NN, NN) for e in range(B)]
+    env = VecWRSN(scs, None, MM, auto_reset=True, render=False, step_budget=int(os.environ.get("WRSN_BUDGET", "0")))
     g = torch.Generator(device="cuda").manual_seed(1)
     r = env.reset()
     for k in range(4):
