@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall budget of the CPU baseline sample (0 = skip)")
     ap.add_argument("--kernel-steps", type=int, default=20, help="steps of the per-kernel timing pass")
-    ap.add_argument("--step-budget", type=int, default=1500,
+    ap.add_argument("--step-budget", type=int, default=1250,
                     help="work units one launch may spend per environment (VecWRSN step_budget); 0 = blocking steps: every "
                          "launch waits for its slowest WRSN.step")
     ap.add_argument("--no-blocking-run", action="store_true", help="skip the additional blocking-mode (step_budget 0) measurement")

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--batch-size", type=int, default=512)
     ap.add_argument("--minibatch-size", type=int, default=64)
     ap.add_argument("--updates", type=int, default=5)
-    ap.add_argument("--step-budget", type=int, default=1500)
+    ap.add_argument("--step-budget", type=int, default=1250)
     ap.add_argument("--infer-chunk", type=int, default=512)
     ap.add_argument("--inference-dtype", default=None, choices=[None, "bf16", "fp16"], help="reduced-precision roll-out inference (update stays float32)")
     args = ap.parse_args()

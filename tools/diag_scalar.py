@@ -10,7 +10,7 @@ NAMES = ["scalar_run", "#loop_iterations", "event_scan", "#scans", "ur_flags+bui
          "decide", "run:post+barrier+mailbox(incl scalar_run)", "svc:precheck", "svc:conn_build", "svc:grid", "min_fitness", "load", "store", "prologue+bind", "-",
          "#services", "#grid_services", "-", "-"]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-env = VecWRSN([synth_scenario(e, 200, 200) for e in range(B)], None, 3, auto_reset=True, render=False, step_budget=int(os.environ.get("WRSN_BUDGET", "1500")))
+env = VecWRSN([synth_scenario(e, 200, 200) for e in range(B)], None, 3, auto_reset=True, render=False, step_budget=int(os.environ.get("WRSN_BUDGET", "1250")))
 g = torch.Generator(device="cuda").manual_seed(1)
 r = env.reset()
 def prof():

@@ -3,7 +3,7 @@ profiles/<tag>_traffic.json (run on the GPU box; the outputs come back through g
 import collections, csv, glob, json, os, shutil, sys
 out, tag = sys.argv[1], sys.argv[2]
 # configuration of the profiled bench command (bench.py attaches `traffic` only to a run of the same configuration)
-cfg = {"envs_per_gpu": 4096, "nodes": 200, "targets": 200, "chargers": 3, "map_size": 100, "step_budget": 1500}
+cfg = {"envs_per_gpu": 4096, "nodes": 200, "targets": 200, "chargers": 3, "map_size": 100, "step_budget": 1250}
 for a in sys.argv[3:]:
     k, v = a.split("="); cfg[k] = int(v)
 min_grid = 64 * cfg["envs_per_gpu"]

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
-B = int(os.environ.get("WRSN_B", "4096")); K = int(os.environ.get("WRSN_K", "3000")); budget = int(os.environ.get("WRSN_BUDGET", "1500"))
+B = int(os.environ.get("WRSN_B", "4096")); K = int(os.environ.get("WRSN_K", "3000")); budget = int(os.environ.get("WRSN_BUDGET", "1250"))
 env = VecWRSN([synth_scenario(7000 + e, 200, 200) for e in range(B)], None, 3, auto_reset=True, step_budget=budget)
 g = torch.Generator(device="cuda").manual_seed(11)
 r = env.reset()
