@@ -121,7 +121,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
         hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
         {
             const int kpt = h->bp2 / WRSN_SORT_THREADS;        // keys per thread of the sort workgroup (0, 1: plain network in LDS)
-            const size_t lb = (size_t)h->bp2 * sizeof(uint32_t);
+            const size_t lb = (size_t)wrsn_sort_lds_bytes();
 #define WRSN_SORT(K_) hipLaunchKernelGGL((wrsn_sort_kernel<K_>), dim3(1), dim3(WRSN_SORT_THREADS), lb, h->stream, h->dev, h->bp2)
             switch (kpt) {
             case 2: WRSN_SORT(2); break;
