@@ -118,7 +118,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     if (timed) (void)hipEventRecord(h->ev[0], h->stream);
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
-        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
+        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
         {
             const int kpt = h->bp2 / WRSN_SORT_THREADS;        // keys per thread of the sort workgroup (0, 1: plain network in LDS)
             const size_t lb = (size_t)wrsn_sort_lds_bytes();

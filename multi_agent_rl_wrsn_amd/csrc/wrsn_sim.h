@@ -2219,9 +2219,10 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
 // seconds to go, plus a surcharge when a node may run dry on the way (packet-exact second + re-routing).
 // wrsn_sort_kernel: stable counting sort of the (work, environment) keys in LDS, one workgroup; ties by environment index: the order
 // is a pure function of the environment states, not of timing.
-__global__ void __launch_bounds__(256) wrsn_estimate_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ action,
+#define WRSN_EST_THREADS 64      // one wave per workgroup: the ~45 scattered cache lines an environment costs are spread over as many CUs as possible
+__global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ action,
                                                             int auto_reset, int BP2) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * WRSN_EST_THREADS + threadIdx.x;
     if (e >= BP2) return;
     if (e >= d.B) { d.order_key[e] = 0xFFFFFFFFu; return; }  // padding sorts to the end
     const WrsnEnvDyn* dy = d.live.dyn + e; const WrsnEnvConst* ec = d.ec + e;
