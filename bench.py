@@ -71,12 +71,12 @@ def cpu_baseline(scenarios, M, seconds, threads):
     return sum(counts) / dt, sum(counts), dt
 
 
-def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup, kernel_steps):
+def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup, kernel_steps, deadline_us=0):
     """One timed run of `steps` VecWRSN.step launches on this rank's shard; returns the local numbers."""
     from multi_agent_rl_wrsn_amd import RolloutStats, VecWRSN
     B = len(scenarios)
     t_set = time.time()
-    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget)
+    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget, step_deadline_us=(deadline_us if budget > 0 else 0))
     env.synchronize()
     t_set = time.time() - t_set
     gen = torch.Generator(device=dev).manual_seed(seed * 7919 + rank)
@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--step-budget", type=int, default=1250,
                     help="work units one launch may spend per environment (VecWRSN step_budget); 0 = blocking steps: every "
                          "launch waits for its slowest WRSN.step")
+    ap.add_argument("--step-deadline-us", type=int, default=0,
+                    help="common deadline of a launch in microseconds after its first wave started (VecWRSN step_deadline_us; 0 = none): "
+                         "waves still running then stop at the next item boundary like waves out of budget")
     ap.add_argument("--no-blocking-run", action="store_true", help="skip the additional blocking-mode (step_budget 0) measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -193,7 +196,7 @@ def main():
         res["sim_seconds_all"], res["zero_steps_all"] = float(cnt[1]), float(cnt[2])
         return float(el[0]), float(cnt[0])
 
-    main_res = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, args.step_budget, args.steps, args.warmup, args.kernel_steps)
+    main_res = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, args.step_budget, args.steps, args.warmup, args.kernel_steps, args.step_deadline_us)
     elapsed, env_steps = reduced(main_res)
     blocking = None
     if args.step_budget > 0 and not args.no_blocking_run:
@@ -236,7 +239,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 (physics) / f32 (observation)", "data": "synthetic",
             "config": {"workload": "%d envs/GPU x %d nodes x %d targets x %d MC, random policy U[0,1)^3, auto-reset, 4x%dx%d observation" % (B, N, T, M, G, G),
-                       "step_budget": args.step_budget, "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G,
+                       "step_budget": args.step_budget, "step_deadline_us": args.step_deadline_us, "envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G,
                        "parallelism": "env-shard x%d" % world},
             "env_steps_timed": env_steps, "sim_ticks_per_s": main_res["sim_seconds_all"] / elapsed,
             "mean_ticks_per_env_step": main_res["sim_seconds_all"] / max(1.0, env_steps),

@@ -147,6 +147,14 @@ int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t 
  * suspension may split a closed-form jump / a batch of the float32 priority pipeline in two); only the launch it is reported in changes. */
 int wrsn_set_step_budget(wrsn_t *h, int32_t work_units);
 
+/* On top of a step budget: a common DEADLINE for the waves of a launch, in microseconds after its first wave started
+ * (0, the default: none).  An environment whose step is still running at the deadline stops at the next grid-item boundary
+ * exactly as if its work budget were used up (status 4, the next wrsn_step goes on with it); every environment still
+ * advances by at least one item per launch.  A wave that starts late thus gets what is left of the launch instead of a
+ * full budget, and the launch ends with (nearly) all wave slots busy.  The requests are the same as ever; WHICH launch
+ * reports a request now depends on timing (the work budget alone is deterministic).  Needs wrsn_set_step_budget > 0. */
+int wrsn_set_step_deadline(wrsn_t *h, int32_t microseconds);
+
 /* WRSN.density_map_to_action (WRSN.py:229-287) with the normalisation of WRSN.step (WRSN.py:293-296), for the
  * `density_map=True` policies of runner/IPPO.py: dmap DEVICE double [B, G, G] (probability map or logits), agent_id
  * DEVICE int32 [B] (< 0: row skipped), action DEVICE double [B, 3] = [x, y, map[argmax] / sum(map >= 99.9th

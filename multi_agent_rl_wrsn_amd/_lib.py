@@ -25,7 +25,7 @@ ENV_FIELDS = ("xmin", "xmax", "ymin", "ymax", "nodes_density", "moving_time_max"
 
 # every entry point include/wrsn_hip.h declares
 EXPORTS = ("wrsn_create", "wrsn_destroy", "wrsn_set_stream", "wrsn_set_scenario", "wrsn_reset", "wrsn_step",
-           "wrsn_set_step_budget", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_set_obs_reuse", "wrsn_set_timing", "wrsn_kernel_times", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
+           "wrsn_set_step_budget", "wrsn_set_step_deadline", "wrsn_density_action", "wrsn_rollout_table", "wrsn_rollout_record", "wrsn_rollout_collect", "wrsn_render", "wrsn_set_obs_reuse", "wrsn_set_timing", "wrsn_kernel_times", "wrsn_peek", "wrsn_sync", "wrsn_counters", "wrsn_synth_network",
            "wrsn_last_error",
            "wrsn_version")
 
@@ -81,6 +81,8 @@ def bind(lib):
     lib.wrsn_step.restype = C.c_int
     lib.wrsn_set_step_budget.argtypes = [vp, C.c_int32]
     lib.wrsn_set_step_budget.restype = C.c_int
+    lib.wrsn_set_step_deadline.argtypes = [vp, C.c_int32]
+    lib.wrsn_set_step_deadline.restype = C.c_int
     lib.wrsn_density_action.argtypes = [vp, vp, vp, vp]
     lib.wrsn_density_action.restype = C.c_int
     lib.wrsn_rollout_table.argtypes = [vp, vp, C.c_int32]
@@ -219,6 +221,9 @@ class RawHandle:
 
     def set_step_budget(self, work_units):
         check(self.lib, self.lib.wrsn_set_step_budget(self._h, int(work_units)))
+
+    def set_step_deadline(self, microseconds):
+        check(self.lib, self.lib.wrsn_set_step_deadline(self._h, int(microseconds)))
 
     def density_action(self, agent_ptr, dmap_ptr, action_ptr):
         check(self.lib, self.lib.wrsn_density_action(self._h, C.c_void_p(agent_ptr), C.c_void_p(dmap_ptr), C.c_void_p(action_ptr)))

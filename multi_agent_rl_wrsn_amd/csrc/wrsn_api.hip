@@ -62,6 +62,7 @@ struct wrsn_handle {
     int waves_per_cu;          // what the occupancy query said for this handle's step kernel (diagnostic)
     long long epoch;           // launch counter of budgeted wrsn_step calls (epoch % 3 selects the in-flight list)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
+    int deadline_ticks;        // wrsn_set_step_deadline in 100 MHz wall-clock ticks, 0 = none
     int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
@@ -111,6 +112,8 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     const int lds = h->lds_env + h->lds_pad;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
+    const int dl = (budget > 0 && h->bp2 > 0) ? h->deadline_ticks : 0;     // the sort kernel zeroes the launch stamp
+    const int taper = h->taper;
     dim3 grid(nenv), block(64);
     long long epoch = 0;
     if (budget > 0) epoch = ++h->epoch;                        // parity selects the hand-off list of the two-launch variant
@@ -142,12 +145,12 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else if (budget > 0 && h->split) {                                                                                 \
         hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 1);                                         \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 1, dl);                                         \
         if (timed) (void)hipEventRecord(h->ev[2], h->stream);                                                          \
         hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv), block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 2);                                         \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 2, dl);                                         \
     } else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | h->taper, mask, out, 0)
+                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl)
     switch (h->npl) {
     case 1: WRSN_LAUNCH(1); break;
     case 2: WRSN_LAUNCH(2); break;
@@ -213,7 +216,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     DeviceGuard guard_(cfg->device);
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
-    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0;
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->deadline_ticks = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0;
     { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
     {   // budget taper over the launch order (units of slots / 8 blocks): start 8 = after the first `slots` blocks, length 16 = down to
         // zero over two times `slots` blocks (the floor of a quarter applies first); WRSN_TAPER="start,len" overrides (diagnostic)
@@ -280,6 +283,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         { int p2 = 1; while (p2 < d.B) p2 <<= 1; h->bp2 = (d.B <= 8192 && !std::getenv("WRSN_NO_ORDER")) ? p2 : 0; }
         if ((rc = dalloc(h, &d.order_key, (size_t)(h->bp2 > 0 ? h->bp2 : 1)))) break;
         if ((rc = dalloc(h, &d.order, (size_t)(h->bp2 > d.B ? h->bp2 : d.B)))) break;
+        if ((rc = dalloc(h, &d.launch_t0, 1))) break;
         if ((rc = dalloc(h, &d.render_agent, B))) break;
         if ((rc = dalloc(h, &d.row_state, B))) break;
         if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
@@ -429,6 +433,13 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
         HIPCHK(hipMemset(h->dev.heavy_n, 0, 2 * sizeof(int32_t)));
     }
     h->step_budget = work_units;
+    return WRSN_OK;
+}
+
+int wrsn_set_step_deadline(wrsn_t* h, int32_t microseconds) {
+    if (!h || microseconds < 0 || microseconds > 10000000) return fail(WRSN_ERR_ARG, "bad step deadline");
+    if (microseconds > 0 && h->bp2 == 0) return fail(WRSN_ERR_STATE, "the launch deadline needs the device-side launch order (at most 8192 environments per handle)");
+    h->deadline_ticks = microseconds * 100;                    // wall_clock64 counts at 100 MHz
     return WRSN_OK;
 }
 

@@ -254,6 +254,7 @@ struct Sim {
     double teps;                                             // energy margin of the "may a node run dry" tests
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
+    long long t_deadline;                                    // wall clock at which this launch stops taking new grid items (0 = none); wave-uniform
     int fit_dirty, map1_valid;                               // a grid service ran since last_minfit was evaluated / map 1 of the observation still stands (wave-uniform)
     int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has
     double last_minfit;
@@ -326,7 +327,7 @@ struct Sim {
         cap = wu(EC()->capacity); thr = wu(EC()->threshold); max_time = wu(EC()->max_time);
         inv_a_b2 = wu((EC()->beta * EC()->beta) / EC()->alpha);
         teps = wu(1e-9 * cap);
-        err = 0; deaths_flag = 0; need_heavy = 0;
+        err = 0; deaths_flag = 0; need_heavy = 0; t_deadline = 0;
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
 
@@ -1325,6 +1326,9 @@ struct Sim {
         if (lane == 0) { SAG()[a].n_conn = cnt; SAG()[a].conn_loc[0] = lx; SAG()[a].conn_loc[1] = ly; }
     }
 
+    // the launch's deadline (wrsn_set_step_deadline) has passed: like an exhausted work budget
+    WDEV bool past_deadline() const { return t_deadline != 0 && (long long)wall_clock64() > t_deadline; }
+
     // ============================================================== GRID LOOP (all lanes, wave-uniform registers)
     // The periodic items of the reference -- Network.operate (k+0.1 setLevels/check_targets, k+1.0 alive check),
     // update_reward (k+1.0) and the Node.operate block (k+0.5, k+1.0) -- are popped here in (time, seq) order until the
@@ -1343,7 +1347,7 @@ struct Sim {
         for (long guard = 0; guard < 4000000L; ++guard) {
             WRSN_PROF_MARK(lh0_)
             if (frozen) break;
-            if (budget > 0 && work >= budget && guard > 0) break;   // out of budget: the next launch asks for this service again
+            if (budget > 0 && guard > 0 && (work >= budget || past_deadline())) break;   // out of budget / time: the next launch asks for this service again
             int k = 1; double bt = ur_time; int64_t bs = ur_seq;
             if (node_time < bt || (node_time == bt && node_seq < bs)) { k = 2; bt = node_time; bs = node_seq; }
             if (net_active && (net_time < bt || (net_time == bt && net_seq < bs))) { k = 0; bt = net_time; bs = net_seq; }
@@ -1368,6 +1372,11 @@ struct Sim {
                 if (safe_ticks == 0 && jf >= 1.0) { work += 4; if (second_is_safe(rrh)) { guarded = true; j = 1; } }
                 if (budget > 0 && j > 1 && j > budget - work) j = (budget - work > 1) ? budget - work : 1;
                 if ((irr || guarded) && j > 1) j = 1;
+                if (t_deadline != 0 && j > 8 && (any_rr || ur_flag)) {
+                    // what is left of the launch, in seconds of the time-parallel steady path (about 0.35 us each, 35 ticks of the 100 MHz clock)
+                    const long long left = (t_deadline - (long long)wall_clock64()) / 35;
+                    if ((long long)j > left) j = left > 8 ? (int)left : 8;
+                }
                 if (j >= 1) {
                     if (!any_rr && !ur_flag && !irr && !guarded) {
                         // nothing but the constant per-second drain: closed form
@@ -1937,7 +1946,7 @@ struct Sim {
             WRSN_P4_MARK(r3_) WRSN_P4_SPAN(11, r0_, r3_) WRSN_P4_CNT(20, 1)
             if (req == REQ_STOP) { stopped = true; break; }
             work += 16;
-            if (budget > 0 && req == REQ_GRID && work >= budget) { suspended = true; break; }
+            if (budget > 0 && req == REQ_GRID && (work >= budget || (guard > 0 && past_deadline()))) { suspended = true; break; }
             switch (req) {
             case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) fit_dirty = 1; map1_valid = 0; grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { svc = precheck(arg); } break;
@@ -2035,7 +2044,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
 template <int NPL, bool HEAVY>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
                                                        const double* __restrict__ action, int auto_reset, int budget, long long epoch, int slots,
-                                                       const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff) {
+                                                       const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff, int deadline) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     // Block b of a step launch takes environment order[b]: the environments sorted by the work their WRSN.step still needs,
@@ -2077,6 +2086,15 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     }
     Sim<NPL, HEAVY> s;
     s.bind(dp, env, lane, smem);
+    if (deadline > 0 && budget > 0 && !reset_call) {         // common deadline of the launch: `deadline` ticks after its first wave started
+        long long t0 = 0;
+        if (lane == 0) {
+            const long long tn = (long long)wall_clock64();
+            const unsigned long long old = atomicCAS((unsigned long long*)dp->launch_t0, 0ull, (unsigned long long)tn);
+            t0 = old ? (long long)old : tn;
+        }
+        s.t_deadline = wu((int64_t)t0) + deadline;
+    }
 #ifdef WRSN_PROFILE
     for (int q_ = 0; q_ < 24; ++q_) s.prof_[q_] = 0;
     const long long kt0_ = clock64();
@@ -2282,6 +2300,7 @@ __global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d,
     int* hist = (int*)smem; int* wsum = hist + NBK + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i <= NBK; i += T) hist[i] = 0;
+    if (tid == 0) *d.launch_t0 = 0;                          // the step launch behind this kernel stamps its start (wrsn_set_step_deadline)
     __syncthreads();
     unsigned key[K]; int bk[K];
 #pragma unroll

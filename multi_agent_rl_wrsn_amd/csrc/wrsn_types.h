@@ -109,6 +109,8 @@ struct WrsnDev {
     int32_t *heavy_n;                 // [2]    heavy service (level BFS, routing rebuild, packet-exact second); list (call & 1)
     int32_t *row_state;               // [B]    what the last environment launch did with the row: 0 left untouched, 1 WRSN.step completed
                                       //        (fresh request), 2 reset / auto-reset request, 3 step still in flight, 4 terminal return
+    long long *launch_t0;             // [1]    wall clock (100 MHz) at which the first wave of the current step launch started; zeroed by the
+                                      //        sort kernel in front of it (wrsn_set_step_deadline)
     int32_t *render_agent;            // [B]    charger whose observation the launch's render pass draws (-1: none); written by the
                                       //        environment kernel for every row, including the rows it leaves untouched
 };

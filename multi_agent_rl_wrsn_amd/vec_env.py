@@ -35,10 +35,13 @@ class VecWRSN:
                 environment whose step is still in flight reports status 4 / agent_id -1 and simply goes on in the
                 next `step` (its agent_id / action row is ignored).  Requests are identical either way; only the
                 launch they appear in differs, so a batch no longer waits for its slowest environment.
+    step_deadline_us: with a step budget, a common deadline of a launch (microseconds after its first wave started): waves still
+                running then stop at the next item boundary like waves out of budget, late waves get what is left of the launch
+                (`wrsn_set_step_deadline`).  Same requests; which launch reports one then depends on timing.
     """
 
     def __init__(self, scenarios, agent_type=None, num_agent=3, map_size=100, warm_up_time=100, device="cuda:0",
-                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0, reuse_obs=True):
+                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0, reuse_obs=True, step_deadline_us=0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("VecWRSN needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -70,6 +73,9 @@ class VecWRSN:
             self.step_budget = int(step_budget)
             if self.step_budget:
                 self._h.set_step_budget(self.step_budget)
+            self.step_deadline_us = int(step_deadline_us)
+            if self.step_deadline_us:
+                self._h.set_step_deadline(self.step_deadline_us)
             # topology build + warm-up + snapshot happen on the device inside set_scenario
             self._h.set_scenarios(scenarios, self.mc_spec)
             B, G = self.num_env, self.map_size

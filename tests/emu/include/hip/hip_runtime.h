@@ -41,6 +41,8 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : hipErrorUnknown; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
+inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long v) { const unsigned long long o = *p; if (o == cmp) *p = v; return o; }
+inline long long wall_clock64() { static long long t_ = 0; return ++t_; }      /* no wall clock here: the deadline option is a GPU-only test */
 struct hipDeviceProp_t { int multiProcessorCount; };
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
 template <typename F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 8; return hipSuccess; }

@@ -286,8 +286,8 @@ def test_step_budget_gives_the_same_requests_as_blocking_steps():
         env.close()
         return hist
 
-    def budgeted(budget):
-        env = VecWRSN(scs, None, 3, step_budget=budget)
+    def budgeted(budget, deadline_us=0):
+        env = VecWRSN(scs, None, 3, step_budget=budget, step_deadline_us=deadline_us)
         r = env.reset(); env.synchronize()
         hist = [[] for _ in range(B)]
         done = np.zeros(B, dtype=bool); nxt = np.zeros(B, dtype=int)      # next action index of every environment
@@ -318,6 +318,14 @@ def test_step_budget_gives_the_same_requests_as_blocking_steps():
         return hist
 
     h0 = blocking(); h1 = budgeted(400)
+    _compare_histories(h0, h1, B)
+    # the same with a launch deadline on top of a generous budget (wrsn_set_step_deadline): which launch reports a request
+    # then depends on timing, the requests do not
+    h2 = budgeted(4000, deadline_us=60)
+    _compare_histories(h0, h2, B)
+
+
+def _compare_histories(h0, h1, B):
     for e in range(B):
         assert len(h1[e]) == len(h0[e]), "environment %d" % e
         for q0, q1 in zip(h0[e], h1[e]):
