@@ -7,7 +7,7 @@ from multi_agent_rl_wrsn_amd import _lib
 _lib._lib = _lib.bind(C.CDLL(os.path.join(ROOT, "tools", "libwrsn_hip_profile3.so")))
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 B = 4096
-env = VecWRSN([synth_scenario(e, 200, 200) for e in range(B)], None, 3, auto_reset=True, render=False, step_budget=int(os.environ.get("WRSN_BUDGET", "1500")))
+env = VecWRSN([synth_scenario(e, 200, 200) for e in range(B)], None, 3, auto_reset=True, render=False, step_budget=int(os.environ.get("WRSN_BUDGET", "1250")), step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")))
 g = torch.Generator(device="cuda").manual_seed(1)
 r = env.reset()
 for k in range(25):
@@ -28,5 +28,6 @@ for rep in range(3):
     act = [int(((t0 < x) & (t1 > x)).sum()) for x in edges[:-1] + np.diff(edges) / 2]
     print("  active waves over time (16 bins): ", act)
     print("  start-time percentiles (us): p50 %.0f p90 %.0f p99 %.0f max %.0f" % tuple(np.percentile(t0, [50, 90, 99, 100])))
+    print("  end-time percentiles (us): p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f" % tuple(np.percentile(t1, [50, 90, 99, 99.9, 100])))
     long_ = (t1 - t0) > 0.6 * (t1 - t0).max()
     print("  long waves: %d, their start p50 %.0f p90 %.0f max %.0f" % (long_.sum(), *np.percentile(t0[long_], [50, 90, 100])))
