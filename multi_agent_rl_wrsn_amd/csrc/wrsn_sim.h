@@ -2088,12 +2088,15 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
     s.bind(dp, env, lane, smem);
     if (deadline > 0 && budget > 0 && !reset_call) {         // common deadline of the launch: `deadline` ticks after its first wave started
         long long t0 = 0;
+        const long long tn = (long long)wall_clock64();      // wave-uniform (s_memrealtime)
         if (lane == 0) {
-            const long long tn = (long long)wall_clock64();
             const unsigned long long old = atomicCAS((unsigned long long*)dp->launch_t0, 0ull, (unsigned long long)tn);
             t0 = old ? (long long)old : tn;
         }
-        s.t_deadline = wu((int64_t)t0) + deadline;
+        {   // lane 0's stamp for the whole wave (v_readlane: the other lanes hold nothing)
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(t0 & 0xffffffffll), 0); const int hi = __builtin_amdgcn_readlane((int)(t0 >> 32), 0);
+            s.t_deadline = (((long long)hi << 32) | (long long)lo) + deadline;
+        }
     }
 #ifdef WRSN_PROFILE
     for (int q_ = 0; q_ < 24; ++q_) s.prof_[q_] = 0;

@@ -42,7 +42,6 @@ inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
 inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long v) { const unsigned long long o = *p; if (o == cmp) *p = v; return o; }
-inline long long wall_clock64() { static long long t_ = 0; return ++t_; }      /* no wall clock here: the deadline option is a GPU-only test */
 struct hipDeviceProp_t { int multiProcessorCount; };
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 256; return hipSuccess; }
 template <typename F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 8; return hipSuccess; }
@@ -77,6 +76,8 @@ inline T emu_exchange(T v, int src_lane) {
     std::memcpy(&r, emu_slots[p][(threadIdx.x & ~63u) | (unsigned)(src_lane & 63)], sizeof(T));   // the source lane of the caller's own wavefront
     return r;
 }
+/* no wall clock here: lane 0 of the wavefront advances a counter and every lane takes ITS reading (a rendezvous): wave-uniform like s_memrealtime */
+inline long long wall_clock64() { static long long t_ = 0; long long v = 0; if ((threadIdx.x & 63u) == 0) v = (t_ += 50); return emu_exchange(v, 0); }
 template <typename T> inline T __shfl(T v, int src) { return emu_exchange(v, src); }
 template <typename T> inline T __shfl_xor(T v, int mask) { return emu_exchange(v, (int)threadIdx.x ^ mask); }
 template <typename T> inline T __shfl_up(T v, int delta) { int s = (int)threadIdx.x - delta; return emu_exchange(v, s < 0 ? (int)threadIdx.x : s); }

@@ -207,6 +207,36 @@ def test_emulated_step_budget_equals_blocking_on_a_200_node_network_with_guarded
     assert np.abs(e0 - e1).max() <= 1e-8 * np.abs(e0).max()
 
 
+def test_emulated_step_deadline_argument_and_same_requests():
+    """wrsn_set_step_deadline: argument checking, and (the emulator has no wall clock -- its stand-in ticks once per reading -- so
+    the deadline falls somewhere inside a step) the requests of a run with a deadline equal the fixture's, like any budgeted run."""
+    from multi_agent_rl_wrsn_amd import _lib
+    z = load_golden("hanoi1000n50_m3_s1")
+    from multi_agent_rl_wrsn_amd.scenario import scenario_from_golden
+    sc, mc = scenario_from_golden(z)
+    ev = _emu([sc], mc, int(z["num_agent"]), map_size=int(z["map_size"]), warm_up_time=float(z["warm_up"]))
+    with pytest.raises(_lib.WrsnError):
+        ev.h.set_step_deadline(-1)
+    ev.h.set_step_budget(100000)
+    ev.h.set_step_deadline(1)                                # 100 readings of the stand-in clock
+    ev.reset()
+    n_susp = 0
+    for k in range(len(z["in_action"])):
+        ev.step([int(z["in_agent"][k])], z["in_action"][k][None])
+        guard = 0
+        while int(ev.status[0]) == 4:
+            n_susp += 1; guard += 1
+            assert guard < 100000
+            ev.step([-1], np.zeros((1, 3)))
+        if z["is_none"][k]:
+            break
+        if not np.isinf(z["reward"][k]):
+            check_decision(z, k, _got(ev), where="deadline", noise=[])
+        if z["terminal"][k]:
+            break
+    assert n_susp > 0
+
+
 def test_emulated_rollout_table_matches_host_accumulation():
     """wrsn_rollout_table: returns per charger / finished episodes / lifetimes / completed steps accumulated by the step
     kernel equal what a host loop over the requests accumulates (RolloutStats layout)."""
