@@ -71,12 +71,13 @@ def cpu_baseline(scenarios, M, seconds, threads):
     return sum(counts) / dt, sum(counts), dt
 
 
-def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup, kernel_steps, deadline_us=0):
+def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup, kernel_steps, deadline_us=0, min_seconds=0.0):
     """One timed run of `steps` VecWRSN.step launches on this rank's shard; returns the local numbers."""
     from multi_agent_rl_wrsn_amd import RolloutStats, VecWRSN
     B = len(scenarios)
     t_set = time.time()
-    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget, step_deadline_us=(deadline_us if budget > 0 else 0))
+    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget, step_deadline_us=(deadline_us if budget > 0 else 0),
+                  reuse_obs=True)                             # the random policy never writes into the state tensor
     env.synchronize()
     t_set = time.time() - t_set
     gen = torch.Generator(device=dev).manual_seed(seed * 7919 + rank)
@@ -104,6 +105,26 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     res = {"elapsed": elapsed, "env_steps": c1["env_steps"] - c0["env_steps"], "sim_seconds": c1["sim_seconds_total"] - c0["sim_seconds_total"],
            "zero_steps": c1["zero_time_steps"] - c0["zero_time_steps"], "exact_ticks": c1["exact_ticks"],
            "table": RolloutStats.gather_table(env.rollout_table()), "t_set": t_set}   # the path's one exchange step (RCCL all-gather)
+    # ---- a timed region of K steps that lasts less than min_seconds is too short for samplers around the run (the driver passes
+    #      --steps 20: ~12 ms): a second region of as many steps as min_seconds needs is timed the same way and reported beside it
+    res["ext"] = None
+    if min_seconds > 0 and elapsed < min_seconds:
+        k2 = int(min(100000, max(steps + 1, steps * min_seconds / max(elapsed, 1e-6) * 1.2)))
+        if dist:                                               # every rank runs the same number of extra steps
+            kt_ = torch.tensor([k2], dtype=torch.int64, device=dev); dist.all_reduce(kt_, op=dist.ReduceOp.MAX); k2 = int(kt_[0])
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            r = env.step(r["agent_id"], policy())
+        torch.cuda.synchronize(dev)
+        if dist:
+            dist.barrier()
+        el2 = time.perf_counter() - t0
+        c2 = env.counters()
+        res["ext"] = {"steps": k2, "elapsed": el2, "env_steps": c2["env_steps"] - c1["env_steps"], "zero_steps": c2["zero_time_steps"] - c1["zero_time_steps"]}
 
     # ---- per-kernel timing pass: HIP events recorded by the library itself on the stream the kernels are launched on
     #      (wrsn_set_timing / wrsn_kernel_times): launch-order kernels, step kernel and observation kernel separately
@@ -124,21 +145,10 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
 
 
 def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start the N ranks here, before this process touches the GPU."""
-    import socket
-    import subprocess
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    raise SystemExit(rc)
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, before this process touches the GPU
+    (multi_agent_rl_wrsn_amd.sharding.launch_ranks; importing the package loads neither torch's GPU runtime nor the HIP library)."""
+    from multi_agent_rl_wrsn_amd.sharding import launch_ranks
+    raise SystemExit(launch_ranks(n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
 
 def main():
@@ -160,6 +170,8 @@ def main():
     ap.add_argument("--step-deadline-us", type=int, default=0,
                     help="common deadline of a launch in microseconds after its first wave started (VecWRSN step_deadline_us; 0 = none): "
                          "waves still running then stop at the next item boundary like waves out of budget")
+    ap.add_argument("--min-seconds", type=float, default=0.1,
+                    help="when the timed region of --steps launches is shorter than this, a second region long enough is timed too and reported as `extended` (0 = off)")
     ap.add_argument("--no-blocking-run", action="store_true", help="skip the additional blocking-mode (step_budget 0) measurement")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -188,15 +200,18 @@ def main():
     t_gen = time.time() - t_gen
 
     def reduced(res):
-        el = torch.tensor([res["elapsed"]], dtype=torch.float64, device=dev)
-        cnt = torch.tensor([res["env_steps"], res["sim_seconds"], res["zero_steps"]], dtype=torch.float64, device=dev)
+        ext = res.get("ext") or {"elapsed": 0.0, "env_steps": 0, "zero_steps": 0}
+        el = torch.tensor([res["elapsed"], ext["elapsed"]], dtype=torch.float64, device=dev)
+        cnt = torch.tensor([res["env_steps"], res["sim_seconds"], res["zero_steps"], ext["env_steps"], ext["zero_steps"]], dtype=torch.float64, device=dev)
         if dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)           # slowest rank
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)          # whole job
         res["sim_seconds_all"], res["zero_steps_all"] = float(cnt[1]), float(cnt[2])
+        if res.get("ext"):
+            res["ext"]["elapsed_all"], res["ext"]["env_steps_all"], res["ext"]["zero_steps_all"] = float(el[1]), float(cnt[3]), float(cnt[4])
         return float(el[0]), float(cnt[0])
 
-    main_res = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, args.step_budget, args.steps, args.warmup, args.kernel_steps, args.step_deadline_us)
+    main_res = measure(torch, dist, dev, scenarios, M, G, rank, args.seed, args.step_budget, args.steps, args.warmup, args.kernel_steps, args.step_deadline_us, args.min_seconds)
     elapsed, env_steps = reduced(main_res)
     blocking = None
     if args.step_budget > 0 and not args.no_blocking_run:
@@ -206,6 +221,7 @@ def main():
         blocking = {"value": bcnt / bel, "unit": "env-steps/s", "steps": bsteps, "ms_per_step": 1e3 * bel / bsteps,
                     "sim_ticks_per_s": bres["sim_seconds_all"] / bel, "mean_ticks_per_env_step": bres["sim_seconds_all"] / max(1.0, bcnt),
                     "zero_time_step_share": bres["zero_steps_all"] / max(1.0, bcnt),
+                    "value_time_advancing": (bcnt - bres["zero_steps_all"]) / bel,
                     "kernels": {"wrsn_step_kernel_ms": 1e3 * bres["env_launch"], "wrsn_obs_kernel_ms": 1e3 * bres["obs_launch"],
                                 "launch_order_kernels_ms": 1e3 * bres["order_launch"], "env_steps_per_launch": bres["units"]},
                     "note": "step_budget 0: every launch runs each WRSN.step to its end and waits for the slowest environment"}
@@ -220,13 +236,14 @@ def main():
     peak = 8000.0
     # HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes (profiles/), attached
     # only when they were taken on THIS configuration (the file names it); null otherwise
-    traffic = None; traffic_src = None
+    traffic = None; traffic_src = None; rocprof_us = None
     this_cfg = {"envs_per_gpu": B, "nodes": N, "targets": T, "chargers": M, "map_size": G, "step_budget": args.step_budget}
     try:
         for tfile in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
             tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
             if tj.get("config") == this_cfg and dom in tj.get("kernels", {}):
                 traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]; traffic_src = "profiles/" + tfile
+                rocprof_us = tj["kernels"][dom].get("rocprof_avg_us")     # average duration of that kernel in the --kernel-trace --stats pass of the same command
                 break
     except Exception:
         traffic = None
@@ -253,13 +270,27 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": per_unit * units, "algorithmic_bytes_per_env_step": {"physics": phys_b, "observation": obs_b},
                          "whole_step_achieved_GBps": (phys_b + obs_b) * value / 1e9, "whole_step_frac": (phys_b + obs_b) * value / 1e9 / peak},
         }
+        if rocprof_us:                                          # the same fraction on the committed rocprofv3 duration of that kernel (same configuration)
+            out["roofline"]["rocprof_avg_us"] = rocprof_us
+            out["roofline"]["frac_rocprof"] = per_unit * units / (rocprof_us * 1e-6) / 1e9 / peak
+        zshare = main_res["zero_steps_all"] / max(1.0, env_steps)
+        out["value_time_advancing"] = value * (1.0 - zshare)   # completed WRSN.step calls that ran simulated time (the rest: bookkeeping returns at t = warm_up_time)
+        if main_res.get("ext"):
+            x = main_res["ext"]
+            out["extended"] = {"steps": x["steps"], "value": x["env_steps_all"] / x["elapsed_all"], "ms_per_step": 1e3 * x["elapsed_all"] / x["steps"],
+                               "value_time_advancing": (x["env_steps_all"] - x["zero_steps_all"]) / x["elapsed_all"],
+                               "note": "the timed region of --steps %d launches lasted %.1f ms; the same loop over %d launches, timed the same way" % (args.steps, 1e3 * elapsed, x["steps"])}
         if blocking is not None:
             out["blocking"] = blocking
         if args.cpu_seconds > 0 and world == 1:
             cores = os.cpu_count() or 1
-            threads = max(1, min(cores, 64))
+            try:
+                usable = len(os.sched_getaffinity(0))           # what this process may run on (a box hands out a share of the host)
+            except Exception:
+                usable = cores
+            threads = max(1, min(usable, 64))
             v, n, dt = cpu_baseline(scenarios[:256], M, args.cpu_seconds, threads)
-            out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "host_cores": cores, "usable_cores": usable, "kind": "port",
                                    "sample": "%d oracle env-steps (incl. get_state) in %.1f s on %d threads, same synthetic networks and action distribution" % (n, dt, threads)}
         print(json.dumps(out), flush=True)
     if dist:

@@ -9,8 +9,8 @@ observation), policy inference (UNet forward + sampling for every environment th
 (transition buffers, density map -> action) and the PPO update; env-steps/s of the roll-out alone and with training.
 `python bench.py` stays the headline (random policy) measurement.
 
-Under torchrun (`python -m torch.distributed.run --nproc-per-node N bench_ippo.py`, BASELINE configs[3]: 8 x 4096 environments)
-every rank rolls out its own environment shard, the actor / critic gradients are averaged with one RCCL all-reduce per minibatch
+`python bench_ippo.py --gpus N` (BASELINE configs[3]: N = 8, 8 x 4096 environments) starts the N ranks itself; under torchrun
+(`python -m torch.distributed.run --nproc-per-node N bench_ippo.py --gpus N`) it joins the launcher's group.  Every rank rolls out its own environment shard, the actor / critic gradients are averaged with one RCCL all-reduce per minibatch
 (`PPOLearner`), the roll-out returns table is all-gathered once per run, and rank 0 prints the line with whole-job totals."""
 import argparse
 import json
@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); without a launcher (WORLD_SIZE unset) this process starts them itself")
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--warmup-iters", type=int, default=1, help="untimed iterations first (MIOpen kernel search for every new convolution shape)")
     ap.add_argument("--envs", type=int, default=4096)
@@ -35,16 +36,26 @@ def main():
     ap.add_argument("--infer-chunk", type=int, default=512)
     ap.add_argument("--inference-dtype", default=None, choices=[None, "bf16", "fp16"], help="reduced-precision roll-out inference (update stays float32)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # launcher-free multi-rank entry: before this process touches torch or the GPU
+        from multi_agent_rl_wrsn_amd.sharding import launch_ranks
+        raise SystemExit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     import numpy as np
     import torch
     from multi_agent_rl_wrsn_amd import BatchedIPPO, RolloutStats, VecWRSN, init_distributed, synth_scenario
     rank, world, local_rank = init_distributed()
+    if world != args.gpus and not (args.gpus == 1 and "WORLD_SIZE" in os.environ):      # torchrun without --gpus: WORLD_SIZE rules
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = torch.distributed if world > 1 else None
+    if dist:                                                   # the RCCL group the ranks really formed
+        one = torch.ones(1, dtype=torch.float64, device=torch.device("cuda", local_rank)); dist.all_reduce(one)
+        if int(one[0]) != world or dist.get_backend() != "nccl":
+            raise SystemExit("process group has %d ranks on backend %s, expected %d on nccl" % (int(one[0]), dist.get_backend(), world))
     torch.manual_seed(0); np.random.seed(rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     B, N, M = args.envs, args.nodes, 3
-    env = VecWRSN([synth_scenario(rank * B + e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev))
+    env = VecWRSN([synth_scenario(rank * B + e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev),
+                  reuse_obs=True)                             # BatchedIPPO only reads the state tensor (index_select / copies)
     algo = BatchedIPPO(dict(batch_size=args.batch_size, minibatch_size=args.minibatch_size, n_updates_per_iteration=args.updates), env,
                        capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk, inference_dtype=args.inference_dtype)
     if args.warmup_iters > 0:

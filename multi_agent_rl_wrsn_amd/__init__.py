@@ -5,11 +5,11 @@ facade and the environment sharding helpers.  Importing the package does not loa
 environment does, and fails loudly when it is missing or no HIP device is present."""
 from .scenario import (DEFAULT_MC_SPEC, DEFAULT_NODE_SPEC, Scenario, load_mc_yaml, load_scenario_yaml,  # noqa: F401
                        scenario_from_golden, synth_batch, synth_scenario)
-from .sharding import RolloutStats, init_distributed, shard_range  # noqa: F401
+from .sharding import RolloutStats, init_distributed, launch_ranks, shard_range  # noqa: F401
 from .vec_env import VecWRSN  # noqa: F401
 from .wrsn import WRSN  # noqa: F401
 from .ippo import BatchedIPPO, PPOLearner, TransitionBuffers, build_networks, select_batch  # noqa: F401
 
 __all__ = ["Scenario", "load_scenario_yaml", "load_mc_yaml", "synth_scenario", "synth_batch", "scenario_from_golden",
-           "DEFAULT_NODE_SPEC", "DEFAULT_MC_SPEC", "VecWRSN", "WRSN", "RolloutStats", "init_distributed", "shard_range",
+           "DEFAULT_NODE_SPEC", "DEFAULT_MC_SPEC", "VecWRSN", "WRSN", "RolloutStats", "init_distributed", "launch_ranks", "shard_range",
            "BatchedIPPO", "PPOLearner", "TransitionBuffers", "build_networks", "select_batch"]

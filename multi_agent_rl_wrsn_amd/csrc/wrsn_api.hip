@@ -51,25 +51,38 @@ int npl_for(int n_node) {
 
 }  // namespace
 
+// nodes-per-lane dispatch: `M_(NPL)` for the handle's register-slot count.  Diagnostic builds (tools/ab_build.sh) compile one slot count only
+// (-DWRSN_ONLY_NPL=4: a quarter of the build time); the product build has all five.
+#ifdef WRSN_ONLY_NPL
+#define WRSN_NPL_SWITCH(npl_, M_, bad_) switch (npl_) { case WRSN_ONLY_NPL: M_(WRSN_ONLY_NPL); break; default: bad_; }
+#else
+#define WRSN_NPL_SWITCH(npl_, M_, bad_) switch (npl_) { case 1: M_(1); break; case 2: M_(2); break; case 4: M_(4); break; case 8: M_(8); break; case 16: M_(16); break; default: bad_; }
+#endif
+
 struct wrsn_handle {
     wrsn_cfg cfg;
     WrsnDev dev;
     hipStream_t stream;
     int npl;
     int scenario_set;
-    int lds_env, lds_obs;
+    int lds_env, lds_lean, lds_obs;   // LDS bytes of an environment wave (full / lean variant of the step kernel), of an observation block
+    int cc_bound;              // largest WrsnEnvConst.conn_bound of the scenarios set so far (-> WrsnDev.CC)
+    hipStream_t stream2;       // the heavy launch of a budgeted step call runs here, beside the lean launch on `stream`
+    hipEvent_t ev_fork, ev_join; int ev2_ok;
+    int cus;                   // compute units of the device
     int slots;                 // wave slots of the device for the step kernel (CUs x resident waves per CU): launch-order dependent budgets
     int waves_per_cu;          // what the occupancy query said for this handle's step kernel (diagnostic)
-    long long epoch;           // launch counter of budgeted wrsn_step calls (epoch % 3 selects the in-flight list)
+    long long epoch;           // counter of wrsn_step calls (its parity selects the hand-off list a budgeted call reads / writes)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     int deadline_ticks;        // wrsn_set_step_deadline in 100 MHz wall-clock ticks, 0 = none
-    int split;                 // budgeted steps as two launches (lean variant + continuation over the hand-off list); diagnostic
+    int split;                 // budgeted steps as lean launch + concurrent heavy launch over the hand-off list (WRSN_SPLIT=1; diagnostic)
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
     int obs_reuse;             // wrsn_set_obs_reuse: the caller keeps the observation rows the library wrote
     int timing;                // record HIP events around the kernels of every wrsn_step (wrsn_set_timing)
     hipEvent_t ev[5];          // before the order kernels, after them, after the step kernel, after the continuation, after the observation
     int ev_ok, ev_obs;         // events created / the last call rendered an observation
+    int ev_rec;                // a wrsn_step has recorded the events since timing was switched on
     int bp2;                   // B rounded up to a power of two when the launch order is sorted on the device (B <= 8192), else 0
     std::vector<void*> allocs;
     WrsnDev* d_dev;            // device copy of `dev`: the environment kernels read it through the constant cache
@@ -107,25 +120,63 @@ int alloc_node_arrays(wrsn_handle* h, WrsnNodeArrays* a) {
     return 0;
 }
 
+// LDS sizes, wave slots and the device copy of the descriptor; again whenever WrsnDev.CC changes
+int configure_launch(wrsn_handle* h) {
+    WrsnDev& d = h->dev;
+    h->lds_env = wrsn_lds_bytes(d.NP, d.M, d.CC, 1);
+    h->lds_lean = wrsn_lds_bytes(d.NP, d.M, d.CC, 0);
+    {   // wave slots of the step kernel on this device (registers and LDS decide): the budget taper of a launch starts behind the blocks
+        // that are resident from the first moment.  Budgeted calls launch the lean variant.
+        int per_cu = 0; hipError_t oe = hipErrorUnknown;
+        const bool lean = h->split != 0;
+        const int lds_b = (lean ? h->lds_lean : h->lds_env) + h->lds_pad;
+#define WRSN_OCC(NPL_) oe = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<NPL_, false>, 64, (size_t)lds_b) \
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<NPL_, true>, 64, (size_t)lds_b)
+        WRSN_NPL_SWITCH(h->npl, WRSN_OCC, oe = hipErrorUnknown)
+#undef WRSN_OCC
+        h->slots = h->cus * 8;
+        if (oe == hipSuccess && per_cu >= 1 && per_cu <= 16) h->slots = h->cus * per_cu;
+        h->waves_per_cu = (oe == hipSuccess) ? per_cu : 0;
+    }
+    HIPCHK(hipMemcpy(h->d_dev, &h->dev, sizeof(WrsnDev), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agent_id, const double* action,
                int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out) {
-    const int lds = h->lds_env + h->lds_pad;
+    const int lds = h->lds_env + h->lds_pad, lds_lean = h->lds_lean + h->lds_pad;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
     const int dl = (budget > 0 && h->bp2 > 0) ? h->deadline_ticks : 0;     // the sort kernel zeroes the launch stamp
     const int taper = h->taper;
     dim3 grid(nenv), block(64);
     long long epoch = 0;
-    if (budget > 0) epoch = ++h->epoch;                        // parity selects the hand-off list of the two-launch variant
+    if (mode == WRSN_MODE_STEP) epoch = ++h->epoch;            // every step call: a hand-off stamp names the one call whose heavy launch owns the environment
+    const bool split = budget > 0 && h->split && h->ev2_ok;
     const bool timed = (mode == WRSN_MODE_STEP) && h->timing && h->ev_ok;
     if (timed) (void)hipEventRecord(h->ev[0], h->stream);
+    // A budgeted step call is two launches side by side.  On the second stream: the full variant of the step kernel over the environments the
+    // previous call's lean launch stopped in front of a heavy service (level BFS, routing rebuild, packet-exact second).  On the caller's
+    // stream: the lean variant (no code for those services, three waves per SIMD) over everybody else.  The heavy launch needs nothing of this
+    // call but the list, so it starts at once and the two overlap; the observation kernel waits for both.
+#define WRSN_HEAVY(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream2, (const WrsnDev*)h->d_dev, \
+                                           0, agent_id, action, 0, budget, epoch, 0, mask, out, 2, 0)
+    if (split) {
+        (void)hipEventRecord(h->ev_fork, h->stream);
+        (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+        WRSN_NPL_SWITCH(h->npl, WRSN_HEAVY, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
+        (void)hipEventRecord(h->ev_join, h->stream2);
+    }
+#undef WRSN_HEAVY
+    const int next_list = split ? (int)((epoch + 1) & 1) : -1;
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
-        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
+        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2,
+                           split ? epoch : 0ll);
         {
             const int kpt = h->bp2 / WRSN_SORT_THREADS;        // keys per thread of the sort workgroup (0, 1: plain network in LDS)
             const size_t lb = (size_t)wrsn_sort_lds_bytes();
-#define WRSN_SORT(K_) hipLaunchKernelGGL((wrsn_sort_kernel<K_>), dim3(1), dim3(WRSN_SORT_THREADS), lb, h->stream, h->dev, h->bp2)
+#define WRSN_SORT(K_) hipLaunchKernelGGL((wrsn_sort_kernel<K_>), dim3(1), dim3(WRSN_SORT_THREADS), lb, h->stream, h->dev, h->bp2, next_list)
             switch (kpt) {
             case 2: WRSN_SORT(2); break;
             case 4: WRSN_SORT(4); break;
@@ -136,31 +187,19 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
             }
 #undef WRSN_SORT
         }
-    }
+    } else if (split) HIPCHK(hipMemsetAsync(h->dev.heavy_n + next_list, 0, sizeof(int32_t), h->stream));
     if (timed) (void)hipEventRecord(h->ev[1], h->stream);
-    // A budgeted step is two launches: the lean variant of the step kernel over all environments (no code for the level BFS,
-    // the routing rebuild and the packet-exact second: no scratch memory), then the full variant over the few environments
-    // the lean one stopped in front of such a service (hand-off list; the other blocks leave at once).
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
-    else if (budget > 0 && h->split) {                                                                                 \
-        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+    else if (split) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds_lean, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 1, dl);                                         \
-        if (timed) (void)hipEventRecord(h->ev[2], h->stream);                                                          \
-        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv), block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 2, dl);                                         \
-    } else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+    else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                             auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl)
-    switch (h->npl) {
-    case 1: WRSN_LAUNCH(1); break;
-    case 2: WRSN_LAUNCH(2); break;
-    case 4: WRSN_LAUNCH(4); break;
-    case 8: WRSN_LAUNCH(8); break;
-    case 16: WRSN_LAUNCH(16); break;
-    default: return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane");
-    }
+    WRSN_NPL_SWITCH(h->npl, WRSN_LAUNCH, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
 #undef WRSN_LAUNCH
-    if (timed) { if (!(budget > 0 && h->split)) (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; }
+    if (timed) (void)hipEventRecord(h->ev[2], h->stream);
+    if (split) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);   // whatever follows on the caller's stream sees both launches
+    if (timed) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; h->ev_rec = 1; }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -216,8 +255,14 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     DeviceGuard guard_(cfg->device);
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
-    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->deadline_ticks = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0;
+    h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->deadline_ticks = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0; h->ev_rec = 0;
+    // WRSN_SPLIT=1: budgeted calls as lean launch + concurrent heavy launch (measured in r03, profiles/r03_split_experiment.log: slower than the
+    // one full launch at every budget -- the hand-off costs an environment the rest of its launch; kept as a diagnostic, parity-tested)
     { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
+    h->stream2 = nullptr; h->ev2_ok = 0; h->cc_bound = 0; h->cus = 256;
+    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess) h->ev2_ok = 1; else (void)hipEventDestroy(h->ev_fork);
+    }
     {   // budget taper over the launch order (units of slots / 8 blocks): start 8 = after the first `slots` blocks, length 16 = down to
         // zero over two times `slots` blocks (the floor of a quarter applies first); WRSN_TAPER="start,len" overrides (diagnostic)
         int ts = 8, tl = 16; const char* e = std::getenv("WRSN_TAPER");
@@ -225,7 +270,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         h->taper = (ts << 16) | (tl << 24);
     }
     { const char* e = std::getenv("WRSN_LDS_PAD"); h->lds_pad = e ? std::atoi(e) : 0; if (h->lds_pad < 0 || h->lds_pad > 100000) h->lds_pad = 0; }
-    { hipDeviceProp_t pr; h->slots = (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount * 8 : 2048; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, cfg->device) == hipSuccess && pr.multiProcessorCount > 0) h->cus = pr.multiProcessorCount; h->slots = h->cus * 8; }
     h->npl = npl_for(cfg->n_node);
     if (h->npl < 0) { delete h; return fail(WRSN_ERR_ARG, "n_node too large"); }
     WrsnDev& d = h->dev;
@@ -239,21 +284,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         int CG = (d.G + 3) / 4; int RG = 256 / CG; if (RG < 1) { delete h; return fail(WRSN_ERR_ARG, "map_size too large"); }
         int RPG = (d.G + RG - 1) / RG; if (RPG > WRSN_OBS_MAXROWS) { delete h; return fail(WRSN_ERR_ARG, "map_size too large for the observation tile"); }
     }
-    h->lds_env = wrsn_lds_bytes(d.NP, d.M);
-    {   // wave slots of the step kernel on this device (registers and LDS decide: 8 per CU up to 256 nodes, 3 at 1 024 nodes x 8 chargers):
-        // the budget taper of a launch starts behind the blocks that are resident from the first moment
-        int per_cu = 0; hipError_t oe = hipErrorUnknown;
-        const int lds_b = h->lds_env + h->lds_pad;
-        switch (h->npl) {
-        case 1: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<1, true>, 64, (size_t)lds_b); break;
-        case 2: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<2, true>, 64, (size_t)lds_b); break;
-        case 4: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<4, true>, 64, (size_t)lds_b); break;
-        case 8: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<8, true>, 64, (size_t)lds_b); break;
-        default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<16, true>, 64, (size_t)lds_b); break;
-        }
-        if (oe == hipSuccess && per_cu >= 1 && per_cu <= 8) h->slots = (h->slots / 8) * per_cu;
-        h->waves_per_cu = (oe == hipSuccess) ? per_cu : 0;
-    }
+    d.CC = 4;                                                  // raised by wrsn_set_scenario to what the scenarios need
     h->lds_obs = wrsn_obs_lds_bytes(d.G, d.NP);
     const size_t B = d.B, NP = d.NP;
     int rc = 0;
@@ -288,6 +319,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.row_state, B))) break;
         if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
         if ((rc = dalloc(h, &d.heavy_n, 2))) break;
+        if ((rc = dalloc(h, &d.heavy_epoch, B))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
     } while (0);
     if (rc) { wrsn_destroy(h); return rc; }
@@ -295,7 +327,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         std::vector<int32_t> ident(B); for (size_t e = 0; e < B; ++e) ident[e] = (int32_t)e;
         if (hipMemcpy(d.order, ident.data(), B * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
     }
-    if (hipMemcpy(h->d_dev, &h->dev, sizeof(WrsnDev), hipMemcpyHostToDevice) != hipSuccess) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
+    if (configure_launch(h) != 0) { wrsn_destroy(h); return fail(WRSN_ERR_HIP, "hipMemcpy"); }
     *out = h;
     return WRSN_OK;
 }
@@ -304,6 +336,8 @@ void wrsn_destroy(wrsn_t* h) {
     if (!h) return;
     DeviceGuard guard_(h->cfg.device);
     if (h->ev_ok) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
+    if (h->ev2_ok) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -355,6 +389,11 @@ int wrsn_set_scenario(wrsn_t* h, int32_t env0, int32_t nenv, const double* node_
     for (int e = 0; e < nenv; ++e) {
         if (ec[e].error == -1) return fail(WRSN_ERR_CAPACITY, "neighbour list capacity exceeded (raise wrsn_cfg.max_degree); env " + std::to_string(env0 + e) + " has " + std::to_string(ec[e].n_edges) + " directed edges");
         if (ec[e].error == -2) return fail(WRSN_ERR_CAPACITY, "coverage list capacity exceeded (raise wrsn_cfg.max_cover); env " + std::to_string(env0 + e));
+    }
+    {   // size the connected-node lists in LDS to the scenarios (WrsnEnvConst.conn_bound, wrsn_topology_kernel)
+        for (int e = 0; e < nenv; ++e) if (ec[e].conn_bound > h->cc_bound) h->cc_bound = ec[e].conn_bound;
+        int cc = ((h->cc_bound + 3) / 4) * 4; cc = cc < 4 ? 4 : (cc > WRSN_CONN_CAP ? WRSN_CONN_CAP : cc);
+        if (cc != h->dev.CC) { h->dev.CC = cc; int rc2 = configure_launch(h); if (rc2) return rc2; }
     }
     WrsnStepOutDev none; std::memset(&none, 0, sizeof(none));
     int rc = launch_env(h, WRSN_MODE_WARMUP, env0, nenv, nullptr, nullptr, 0, nullptr, none);
@@ -408,6 +447,7 @@ int wrsn_set_timing(wrsn_t* h, int32_t on) {
         for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
         h->ev_ok = 1;
     }
+    if (!on || !h->timing) h->ev_rec = 0;
     h->timing = on ? 1 : 0;
     return WRSN_OK;
 }
@@ -415,6 +455,7 @@ int wrsn_set_timing(wrsn_t* h, int32_t on) {
 int wrsn_kernel_times(wrsn_t* h, float* ms) {
     if (!h || !ms) return fail(WRSN_ERR_ARG, "null argument");
     if (!h->ev_ok || !h->timing) return fail(WRSN_ERR_STATE, "wrsn_set_timing(h, 1) first");
+    if (!h->ev_rec) return fail(WRSN_ERR_STATE, "no wrsn_step has run since wrsn_set_timing(h, 1)");
     WRSN_ON_DEVICE(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     ms[0] = ms[1] = ms[2] = ms[3] = 0.f;

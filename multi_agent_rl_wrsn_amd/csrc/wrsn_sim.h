@@ -20,8 +20,6 @@
 #include "wrsn_types.h"
 
 #define WDEV __device__ __forceinline__
-#define WRSN_CHG_MAX(NP_) ((NP_) > 512 ? 6 : 8)   // nodes under charge handled by the time-parallel steady batch (six above 512 nodes: three
-                                           // environments of 1 024 nodes x 8 chargers then fit the 160 KB of LDS of a CU instead of two)
 // Diagnostic build only (-DWRSN_PROFILE, tools/build_profile.sh): per-phase cycle totals per environment.  Stamps go
 // to a buffer of their own (WrsnDev.counters) and no output is computed from them; the product build has none.
 #if defined(WRSN_PROFILE) && WRSN_PROFILE == 4
@@ -235,7 +233,7 @@ struct Sim {
     // identity / geometry.  Pointers are not kept as members: they are derived on demand from the device descriptor
     // (scalar loads from the constant cache) and from the LDS base, which keeps the hot per-second loop small in
     // registers.
-    int env, lane, N, T, M, NP, use_snap;
+    int env, lane, N, T, M, NP, CC, use_snap;           // CC: capacity of a connected-node list in LDS (WrsnDev.CC)
     const WrsnDev* dp;
     double* smem_;
     // node registers (per lane)
@@ -287,23 +285,23 @@ struct Sim {
     WDEV const U4* TCP() const { return (const U4*)(dp->tcp + (size_t)env * dp->TP * 4); }
     WDEV double* RING() const { return (use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP; }
     WDEV double* LOGBUF() const { return (use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP; }
-    // ---- LDS carve-up (must match wrsn_lds_bytes)
+    // ---- LDS carve-up (must match wrsn_lds_bytes).  The lean variant never touches the cached receivers: they stay in HBM.
     WDEV double* SRR() const { return smem_; }
     WDEV double* SU() const { return smem_ + NP; }
     WDEV int32_t* SLS() const { return (int32_t*)(smem_ + 3 * NP); }
-    WDEV int32_t* SRCV() const { return SLS() + NP; }
+    WDEV int32_t* SRCV() const { static_assert(HEAVY, "cached receivers are staged by the full variant only"); return SLS() + NP; }
     // time-parallel steady batch: float CS per node, records / per-second table of the (few) nodes being charged
-    WDEV float* SCSF() const { return (float*)(smem_ + 4 * NP); }
-    WDEV double* SCHGREC() const { return smem_ + 4 * NP + NP / 2; }                       // [CHG_MAX][8]: E, d1, d2, rr, node, E_final, CS
+    WDEV float* SCSF() const { return (float*)(smem_ + 3 * NP + (HEAVY ? NP : NP / 2)); }
+    WDEV double* SCHGREC() const { return (double*)SCSF() + NP / 2; }                    // [CHG_MAX][8]: E, d1, d2, rr, node, E_final, CS
     WDEV double* SCHGTAB() const { return SCHGREC() + 8 * kChgMax; }                 // [CHG_MAX][64] energy at the reward instant of second s
     WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(SCHGTAB() + 64 * kChgMax); }
     WDEV WrsnThread* STH() const { return (WrsnThread*)(SAG() + M); }
     WDEV double* SCT() const { return (double*)(STH() + 2 * M); }
     WDEV int64_t* SCS() const { return (int64_t*)(SCT() + (M + 1)); }
-    WDEV double* SCONNXY() const { return (double*)(SCS() + (M + 1)); }                 // [M][CONN_CAP][2] position of every connected node
-    WDEV double* SURRATE() const { return SCONNXY() + 2 * M * WRSN_CONN_CAP; }
-    WDEV double* SURACC() const { return SURRATE() + M * WRSN_CONN_CAP; }
-    WDEV double* SREQD() const { return SURACC() + M * WRSN_CONN_CAP; }                 // [0] time limit, [1] now, [2] seq (as int64), [3] spare
+    WDEV double* SCONNXY() const { return (double*)(SCS() + (M + 1)); }                 // [M][CC][2] position of every connected node
+    WDEV double* SURRATE() const { return SCONNXY() + 2 * M * CC; }
+    WDEV double* SURACC() const { return SURRATE() + M * CC; }
+    WDEV double* SREQD() const { return SURACC() + M * CC; }                            // [0] time limit, [1] now, [2] seq (as int64), [3] spare
     WDEV Scalar* SS() const { return (Scalar*)(SREQD() + 4); }
     WDEV int32_t* SREQ() const { return (int32_t*)(EC() + 1); }                           // [0] request, [1] argument, [2] live connections, [3] flags
     WDEV int32_t* SCA() const { return SREQ() + 4; }
@@ -311,12 +309,12 @@ struct Sim {
     WDEV int32_t* SCP() const { return SCTR() + (M + 1); }
     WDEV int32_t* SURN() const { return SCP() + (M + 1); }
     WDEV int16_t* SCONN() const { return (int16_t*)(SURN() + 1); }
-    WDEV int16_t* SURIDX() const { return SCONN() + M * WRSN_CONN_CAP; }
-    WDEV int16_t* SURAGENT() const { return SURIDX() + M * WRSN_CONN_CAP; }
+    WDEV int16_t* SURIDX() const { return SCONN() + M * CC; }
+    WDEV int16_t* SURAGENT() const { return SURIDX() + M * CC; }
 
     // -------------------------------------------------------------- setup
     WDEV void bind(const WrsnDev* dp_, int env_, int lane_, double* smem) {
-        dp = dp_; env = env_; lane = lane_; M = dp_->M; NP = dp_->NP;
+        dp = dp_; env = env_; lane = lane_; M = dp_->M; NP = dp_->NP; CC = dp_->CC;
         smem_ = smem; use_snap = 0;
         {   // stage the constants of this environment in LDS
             const uint64_t* g = (const uint64_t*)(dp_->ec + env_); uint64_t* l = (uint64_t*)EC();
@@ -419,7 +417,8 @@ struct Sim {
             const bool real = i < N;                       // the padding up to NP is never read nor written back
             E[j] = real ? a.E[nb + i] : 0.0; CS[j] = real ? a.CS[nb + i] : 0.0; d1[j] = real ? a.d1[nb + i] : 0.0; d2[j] = real ? a.d2[nb + i] : 0.0;
             SRR()[i] = real ? a.RR[nb + i] : 0.0;
-            int ls = real ? a.ls[nb + i] : 0; SLS()[i] = ls; SRCV()[i] = real ? a.rcv[nb + i] : -1;
+            int ls = real ? a.ls[nb + i] : 0; SLS()[i] = ls;
+            if constexpr (HEAVY) SRCV()[i] = real ? a.rcv[nb + i] : -1;
             am |= (unsigned)(ls & 1) << j;
         }
         const WrsnEnvDyn* dy = a.dyn + env;
@@ -436,7 +435,10 @@ struct Sim {
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = gt[w];
         const int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
         const double* gr = a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2;
-        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { SCONN()[w] = gc[w]; SCONNXY()[2 * w] = gr[2 * w]; SCONNXY()[2 * w + 1] = gr[2 * w + 1]; }
+        for (int w = lane; w < M * CC; w += 64) {             // list m at stride WRSN_CONN_CAP in HBM, CC in LDS
+            const int g = (w / CC) * WRSN_CONN_CAP + (w % CC);
+            SCONN()[w] = gc[g]; SCONNXY()[2 * w] = gr[2 * g]; SCONNXY()[2 * w + 1] = gr[2 * g + 1];
+        }
         for (int w = lane; w <= M; w += 64) { SCTR()[w] = 0; SCP()[w] = 0; SCA()[w] = 0; SCT()[w] = 0; SCS()[w] = 0; }
         if (lane == 0) { SREQ()[0] = 0; SREQ()[1] = 0; SREQ()[2] = dy->n_connected; SS()->n_events = dy->n_events; SURN()[0] = 0; }
         __syncthreads();
@@ -452,7 +454,12 @@ struct Sim {
             if (i < N) {                                   // arrays nothing touched since load() are not written back
                 a.E[nb + i] = E[j]; a.RR[nb + i] = SRR()[i];
                 if (dirty & 4) a.CS[nb + i] = CS[j];
-                if (dirty & 1) { a.d1[nb + i] = d1[j]; a.d2[nb + i] = d2[j]; a.rcv[nb + i] = SRCV()[i]; }
+                if (dirty & 1) {
+                    a.d1[nb + i] = d1[j]; a.d2[nb + i] = d2[j];
+                    // (the lean variant never changes the routing cache; it writes it only when an auto-reset restores the snapshot, and
+                    //  then the receivers, which it does not stage, go from the snapshot to the live array directly)
+                    if constexpr (HEAVY) a.rcv[nb + i] = SRCV()[i]; else a.rcv[nb + i] = dp->snap.rcv[nb + i];
+                }
                 if (dirty & 2) a.ls[nb + i] = SLS()[i];
             }
         }
@@ -472,7 +479,10 @@ struct Sim {
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) gt[w] = lt[w];
         int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
         double* gr = a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2;
-        for (int w = lane; w < M * WRSN_CONN_CAP; w += 64) { gc[w] = SCONN()[w]; gr[2 * w] = SCONNXY()[2 * w]; gr[2 * w + 1] = SCONNXY()[2 * w + 1]; }
+        for (int w = lane; w < M * CC; w += 64) {
+            const int g = (w / CC) * WRSN_CONN_CAP + (w % CC);
+            gc[g] = SCONN()[w]; gr[2 * g] = SCONNXY()[2 * w]; gr[2 * g + 1] = SCONNXY()[2 * w + 1];
+        }
         WRSN_PROF_ADD(11)
     }
 
@@ -997,7 +1007,7 @@ struct Sim {
     // CURRENT location (a stale "charging" charger may be on the move); node positions were cached by conn_build
     WDEV double conn_rate_of(int m, int k, int i) const {
         (void)i;
-        const double* xy = SCONNXY() + 2 * (m * WRSN_CONN_CAP + k);
+        const double* xy = SCONNXY() + 2 * (m * CC + k);
         double dd = dist2(xy[0], xy[1], SAG()[m].loc[0], SAG()[m].loc[1]) + EC()->beta;
         return EC()->alpha / (dd * dd);
     }
@@ -1205,7 +1215,7 @@ struct Sim {
             if (SAG()[m].status == 0 || !SAG()[m].type_charging) continue;
             const int nc = SAG()[m].n_conn;
             for (int k = 0; k < nc; ++k) {
-                const int i = SCONN()[m * WRSN_CONN_CAP + k];
+                const int i = SCONN()[m * CC + k];
                 if (!(SLS()[i] & 1)) continue;
                 SURIDX()[n] = (int16_t)i; SURAGENT()[n] = (int16_t)m; SURRATE()[n] = conn_rate_of(m, k, i); SURACC()[n] = 0.0; ++n;
             }
@@ -1315,14 +1325,14 @@ struct Sim {
             unsigned long long mk = __ballot(in);
             if (in) {
                 int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
-                if (pos < WRSN_CONN_CAP) {
-                    SCONN()[a * WRSN_CONN_CAP + pos] = (int16_t)i;
-                    SCONNXY()[2 * (a * WRSN_CONN_CAP + pos)] = px; SCONNXY()[2 * (a * WRSN_CONN_CAP + pos) + 1] = py;
+                if (pos < CC) {
+                    SCONN()[a * CC + pos] = (int16_t)i;
+                    SCONNXY()[2 * (a * CC + pos)] = px; SCONNXY()[2 * (a * CC + pos) + 1] = py;
                 }
             }
             cnt += __popcll(mk);
         }
-        if (cnt > WRSN_CONN_CAP) { err = -9; cnt = WRSN_CONN_CAP; }
+        if (cnt > CC) { err = -9; cnt = CC; }                 // cannot happen: CC bounds the nodes any disc of the charging range holds (wrsn_topology_kernel)
         if (lane == 0) { SAG()[a].n_conn = cnt; SAG()[a].conn_loc[0] = lx; SAG()[a].conn_loc[1] = ly; }
     }
 
@@ -1573,7 +1583,7 @@ struct Sim {
         const int nc = SAG()[a].n_conn;
         double cr = SAG()[a].charging_rate; int cnt = 0;
         for (int k = 0; k < nc; ++k) {
-            int i = SCONN()[a * WRSN_CONN_CAP + k];
+            int i = SCONN()[a * CC + k];
             if (!(SLS()[i] & 1)) continue;
             double r = conn_rate_of(a, k, i);
             SRR()[i] += sign * r; cr += sign * r; cnt++;
@@ -1600,7 +1610,7 @@ struct Sim {
             double nf = floor(tmp); if (nf == tmp) nf -= 1.0;          // unit sub-steps that are not the last one
             // rate this sub-step would connect with
             double cr = 0.0; const int nc = SAG()[a].n_conn;
-            for (int k = 0; k < nc; ++k) { int i = SCONN()[a * WRSN_CONN_CAP + k]; if (SLS()[i] & 1) cr += conn_rate_of(a, k, i); }
+            for (int k = 0; k < nc; ++k) { int i = SCONN()[a * CC + k]; if (SLS()[i] & 1) cr += conn_rate_of(a, k, i); }
             if (cr > 0.0) { double ne = floor((SAG()[a].energy - EC()->mc_threshold) / cr) - 1.0; if (ne < nf) nf = ne; }
             if (nf > 100000.0) nf = 100000.0;
             int n = (int)nf;
@@ -1946,7 +1956,9 @@ struct Sim {
             WRSN_P4_MARK(r3_) WRSN_P4_SPAN(11, r0_, r3_) WRSN_P4_CNT(20, 1)
             if (req == REQ_STOP) { stopped = true; break; }
             work += 16;
-            if (budget > 0 && req == REQ_GRID && (work >= budget || (guard > 0 && past_deadline()))) { suspended = true; break; }
+            // (guard > 0: whatever the budget -- a user budget of a few units, or the tapered share of a late block -- the first request of a launch
+            //  is served, so that every environment advances by at least one grid item per launch)
+            if (budget > 0 && req == REQ_GRID && guard > 0 && (work >= budget || past_deadline())) { suspended = true; break; }
             switch (req) {
             case REQ_GRID: { WRSN_PROF_T0 WRSN_P4_CNT(21, 1) fit_dirty = 1; map1_valid = 0; grid_run(SREQD()[0], (arg & 1) != 0, SREQ()[3] != 0, (arg & 2) ? ((const int64_t*)SREQD())[3] : (int64_t)-1); WRSN_PROF_ADD(1) } break;
             case REQ_PRECHECK: { svc = precheck(arg); } break;
@@ -1971,8 +1983,15 @@ struct Sim {
 //                     restores the snapshot into d.live and emits the reset request instead        (WRSN.py:66-75)
 // Two kernels so that the event machine and every O(N) routine are instantiated once per code object.
 // two waves per SIMD (256 registers) for up to 256 nodes: the event machine is latency-bound, a second wave hides it
+// The full variant keeps 256 registers (two waves per SIMD up to 256 nodes, one above); the lean variant -- the common path of a budgeted
+// step, without the level BFS / routing rebuild / packet-exact second -- is compiled for THREE waves per SIMD (168 registers, and an
+// LDS footprint of at most 13.6 KB so that twelve environments share a CU): the event machine and the grid loop are latency-bound serial
+// code, and a third resident wave hides what two leave idle (SQ_WAIT_ANY 49 % at two waves).
 #ifndef WRSN_WAVES_PER_SIMD
 #define WRSN_WAVES_PER_SIMD(NPL_) ((NPL_) <= 4 ? 2 : 1)
+#endif
+#ifndef WRSN_WAVES_PER_SIMD_LEAN
+#define WRSN_WAVES_PER_SIMD_LEAN(NPL_) ((NPL_) <= 4 ? 3 : 1)
 #endif
 template <int NPL>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kernel(const WrsnDev* __restrict__ dp, int env0) {
@@ -2002,7 +2021,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     for (int w = lane; w < s.M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = 0;
     uint64_t* lt = (uint64_t*)s.STH();
     for (int w = lane; w < 2 * s.M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = 0;
-    for (int w = lane; w < s.M * WRSN_CONN_CAP; w += 64) { s.SCONN()[w] = 0; s.SCONNXY()[2 * w] = 0.0; s.SCONNXY()[2 * w + 1] = 0.0; }
+    for (int w = lane; w < s.M * s.CC; w += 64) { s.SCONN()[w] = 0; s.SCONNXY()[2 * w] = 0.0; s.SCONNXY()[2 * w + 1] = 0.0; }
     for (int w = lane; w <= s.M; w += 64) { s.SCTR()[w] = 0; s.SCP()[w] = 0; s.SCA()[w] = 0; s.SCT()[w] = 0; s.SCS()[w] = 0; }
     __syncthreads();
     if (lane == 0) {
@@ -2039,27 +2058,37 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
 }
 
 // `handoff`: 0 = the only environment launch of this call (full variant: blocking steps, resets);
-//            1 = lean launch of a budgeted step: an environment that meets a heavy service goes on the hand-off list;
-//            2 = continuation launch (full variant) over that list, block b takes its b-th entry.
+//            1 = lean launch of a budgeted step call: an environment that meets a heavy service is stamped and listed for the NEXT call's
+//                heavy launch; environments stamped for THIS call are left alone (the heavy launch beside this one owns them);
+//            2 = heavy launch (full variant) over the list the previous call's lean launch wrote: block b takes its b-th entry.
 template <int NPL, bool HEAVY>
-__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id,
-                                                       const double* __restrict__ action, int auto_reset, int budget, long long epoch, int slots,
-                                                       const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff, int deadline) {
+__device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
+                                              const double* __restrict__ action, int auto_reset, int budget, long long epoch,
+                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem);
+
+template <int NPL, bool HEAVY>
+__global__ void __launch_bounds__(64, HEAVY ? WRSN_WAVES_PER_SIMD(NPL) : WRSN_WAVES_PER_SIMD_LEAN(NPL))
+wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id, const double* __restrict__ action, int auto_reset,
+                 int budget, long long epoch, int slots, const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff, int deadline) {
     extern __shared__ double smem[];
-    const int lane = threadIdx.x;
     // Block b of a step launch takes environment order[b]: the environments sorted by the work their WRSN.step still needs,
     // longest first (wrsn_estimate_kernel / wrsn_sort_kernel run in front of every step launch).  The duration of a WRSN.step is
     // heavy-tailed and a launch ends with its last wave, so the long jobs have to start first; every environment appears exactly once
     // in the order, so a launch owns an environment through one block only.
+    // The heavy launch has one block per environment of the batch too; block b takes entry b of the list and the blocks behind the end of the
+    // list leave at once (the host does not know its length).
     int env = blockIdx.x;
-    const int hand_l = (int)(epoch & 1);
     if (handoff == 2) {
-        if ((int)blockIdx.x >= dp->heavy_n[hand_l]) return;
-        env = dp->heavy_list[(size_t)hand_l * dp->B + blockIdx.x];
+        if ((int)blockIdx.x >= dp->heavy_n[(int)(epoch & 1)]) return;
+        env = dp->heavy_list[(size_t)(epoch & 1) * dp->B + blockIdx.x];
+        // (a reset between the two calls takes the stamp away; a row the caller marks -2 is left alone -- the lean launch of the next call
+        //  finds it in flight, unstamped, and hands it over again)
+        if (env < 0 || env >= dp->B || dp->heavy_epoch[env] != epoch || agent_id[env] == -2) return;
     } else if (!reset_call) {
         env = dp->order[blockIdx.x];
+        if (env < 0 || env >= dp->B) return;
+        if (handoff == 1 && dp->heavy_epoch[env] == epoch) return;              // this call's heavy launch owns the environment
         if (budget > 0) {
-            if (blockIdx.x == 0 && lane == 0) dp->heavy_n[hand_l ^ 1] = 0;   // the hand-off list of the next call (last read by the continuation launch before this call)
             // blocks are dispatched in index order: a block far behind the first `slots` ones starts late, and what it is
             // allowed to spend shrinks accordingly so that the launch does not wait for late long jobs
             // (`slots` packs three launch parameters: wave slots of the device, block at which the taper starts, blocks over which the
@@ -2073,17 +2102,26 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
         }
     }
     if (env < 0 || env >= dp->B) return;
+    wrsn_step_env<NPL, HEAVY>(dp, env, reset_call, agent_id, action, auto_reset, budget, epoch, env_mask, out, handoff, deadline, smem);
+}
+
+template <int NPL, bool HEAVY>
+__device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
+                                              const double* __restrict__ action, int auto_reset, int budget, long long epoch,
+                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem) {
+    const int lane = threadIdx.x;
     bool do_reset = reset_call != 0;
     // a row nobody handles in this launch is not rendered and none of its outputs is touched
     if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
     int aid = -1, resume = 0;
-    if (handoff == 2) resume = 1;                          // handed over by the lean launch of this call: the step is in flight
+    if (handoff == 2) resume = 1;                          // handed over by the previous call's lean launch: the step is in flight
     else if (!reset_call) {
         aid = agent_id[env];
         if (aid == -2) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
         resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
+    if (reset_call && lane == 0) dp->heavy_epoch[env] = 0; // a reset environment is nobody's hand-off any more
     Sim<NPL, HEAVY> s;
     s.bind(dp, env, lane, smem);
     if (deadline > 0 && budget > 0 && !reset_call) {         // common deadline of the launch: `deadline` ticks after its first wave started
@@ -2187,9 +2225,10 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
             dp->render_agent[env] = -1; dp->row_state[env] = 3;
-            if (!HEAVY && s.need_heavy) {                    // the continuation launch of this call goes on with it
-                const int pos = atomicAdd(&dp->heavy_n[hand_l], 1);
-                dp->heavy_list[(size_t)hand_l * dp->B + pos] = env;
+            if (!HEAVY && s.need_heavy) {                    // the heavy launch of the next call goes on with it
+                const int nl = (int)((epoch + 1) & 1);
+                const int pos = atomicAdd(&dp->heavy_n[nl], 1);
+                dp->heavy_list[(size_t)nl * dp->B + pos] = env; dp->heavy_epoch[env] = epoch + 1;
             }
         }
         if (lane == 0 && !susp) {
@@ -2242,7 +2281,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_step_kernel
 // is a pure function of the environment states, not of timing.
 #define WRSN_EST_THREADS 64      // one wave per workgroup: the ~45 scattered cache lines an environment costs are spread over as many CUs as possible
 __global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ action,
-                                                            int auto_reset, int BP2) {
+                                                            int auto_reset, int BP2, long long heavy_call) {
     const int e = blockIdx.x * WRSN_EST_THREADS + threadIdx.x;
     if (e >= BP2) return;
     if (e >= d.B) { d.order_key[e] = 0xFFFFFFFFu; return; }  // padding sorts to the end
@@ -2261,7 +2300,8 @@ __global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev
         st[m] = a->status; td[m] = a->t_done; lx[m] = a->loc[0]; ly[m] = a->loc[1];
     }
     double w = 0.0;
-    if (aid != -2 && !(auto_reset && term_p)) {
+    // (heavy_call != 0: a budgeted call -- environments stamped for its heavy launch are skipped by the lean launch: no work, sorted to the end)
+    if (aid != -2 && !(auto_reset && term_p) && !(heavy_call != 0 && d.heavy_epoch[e] == heavy_call)) {
         double t_first = 1.0e30;
 #pragma unroll
         for (int m = 0; m < WRSN_MAX_MC; ++m) {
@@ -2297,13 +2337,16 @@ __global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev
 #define WRSN_ORDER_BUCKETS 2048
 static inline int wrsn_sort_lds_bytes() { return (WRSN_ORDER_BUCKETS + 1 + WRSN_SORT_THREADS / 64 + 1) * 4; }
 template <int K>
-__global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d, int BP2) {
+__global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d, int BP2, int next_list) {
     extern __shared__ double smem[];
     constexpr int NBK = WRSN_ORDER_BUCKETS, T = WRSN_SORT_THREADS, NW = T / 64, PER = (NBK + 1 + T - 1) / T;
     int* hist = (int*)smem; int* wsum = hist + NBK + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i <= NBK; i += T) hist[i] = 0;
-    if (tid == 0) *d.launch_t0 = 0;                          // the step launch behind this kernel stamps its start (wrsn_set_step_deadline)
+    if (tid == 0) {
+        *d.launch_t0 = 0;                                    // the step launch behind this kernel stamps its start (wrsn_set_step_deadline)
+        if (next_list >= 0) d.heavy_n[next_list] = 0;        // the hand-off list the lean launch behind this kernel fills for the next call
+    }
     __syncthreads();
     unsigned key[K]; int bk[K];
 #pragma unroll
@@ -2453,7 +2496,16 @@ __global__ void __launch_bounds__(64) wrsn_topology_kernel(WrsnDev d, int env0) 
     }
     if (lane == 0) tc_off[d.TP] = tbase;
     if (tbase > d.CCAP) error = -2;
+    // connected_nodes of a charger (MobileCharger.py:55-58) are the nodes inside a disc of the charging range: any two of them are at most
+    // two ranges apart, so the list never holds more nodes than the fullest disc of twice the range around a node does
+    int cbound = 1;
+    {
+        const double r2 = 2.0 * ec->charging_range;
+        for (int i = lane; i < N; i += 64) { int c = 0; for (int k = 0; k < N; ++k) if (dist2(nx[k], ny[k], nx[i], ny[i]) <= r2) c++; cbound = c > cbound ? c : cbound; }
+        cbound = (int)wv_max((double)cbound);
+    }
     if (lane == 0) {
+        ec->conn_bound = cbound;
         ec->frame[0] = x0; ec->frame[1] = x1; ec->frame[2] = y0; ec->frame[3] = y1;
         ec->density = (double)N / ((x1 - x0) * (y1 - y0));
         ec->moving_time_max = dist2(x0, y0, x1, y1) / ec->velocity;

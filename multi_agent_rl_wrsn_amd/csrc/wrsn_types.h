@@ -6,7 +6,8 @@
 #define WRSN_WAVE 64
 #define WRSN_MAX_MC 8                    // mobile chargers per environment
 #define WRSN_MAX_TH (2 * WRSN_MAX_MC)    // operate_step processes alive at once (current + superseded)
-#define WRSN_CONN_CAP 32                 // nodes inside one charger's charging range
+#define WRSN_CONN_CAP 32                 // nodes inside one charger's charging range: stride of the connected-node lists in HBM (the lists in LDS are
+                                         // sized to the scenario: WrsnDev.CC <= WRSN_CONN_CAP)
 #define WRSN_RING 10                     // Node.log window (Node.py:71-77)
 
 // run modes of the environment kernel
@@ -21,7 +22,8 @@ struct WrsnEnvConst {
     double mc_capacity, mc_threshold, velocity, pm, charging_range, alpha, beta, epsilon;
     double bs[2], frame[4], density, moving_time_max, charging_time_max, avg_nodes_agent;
     double e_recv, d0, warm_up_time;
-    int32_t n_node, n_target, n_edges, n_cover, error, pad;
+    int32_t n_node, n_target, n_edges, n_cover, error;
+    int32_t conn_bound;               // upper bound of len(MobileCharger.connected_nodes): the most nodes within twice the charging range of one node
 };
 
 // MobileCharger object state (MobileCharger.py:6-32) + the per-agent lists WRSN keeps (WRSN.py:33-38)
@@ -87,7 +89,9 @@ struct WrsnNodeArrays {
 };
 
 struct WrsnDev {
-    int32_t B, N, T, M, G, NP, TP, ECAP, CCAP, pad;
+    int32_t B, N, T, M, G, NP, TP, ECAP, CCAP;
+    int32_t CC;                       // capacity of a charger's connected-node list in LDS: the largest number of nodes any disc of the charging
+                                      // range can hold in this handle's scenarios (a multiple of 4, <= WRSN_CONN_CAP; wrsn_set_scenario)
     WrsnEnvConst *ec;                 // [B]
     double *node_x, *node_y, *dist_bs;   // [B][NP]
     double *target_x, *target_y;      // [B][TP]
@@ -105,8 +109,13 @@ struct WrsnDev {
     int64_t *counters;                // [4]
     uint32_t *order_key;              // [BP2]  launch order of a step call, longest job first: (0xFFFF - estimated work) << 13 | environment,
     int32_t *order;                   // [BP2]  sorted ascending; order[b] = environment of block b (BP2 = B rounded up to a power of two)
-    int32_t *heavy_list;              // [2][B] hand-off of a budgeted step call: environments the lean launch stopped in front of a
-    int32_t *heavy_n;                 // [2]    heavy service (level BFS, routing rebuild, packet-exact second); list (call & 1)
+    // Hand-off of a budgeted step call (wrsn_set_step_budget): the lean variant of the step kernel holds no code for the level BFS, the routing
+    // rebuild and the packet-exact second; an environment that meets one of them in call k stops in front of it, is appended to list
+    // (k + 1) & 1 and stamped heavy_epoch = k + 1.  Call k + 1 runs the full variant over that list on a second stream, BESIDE its lean
+    // launch, which leaves every environment stamped k + 1 alone.
+    int32_t *heavy_list;              // [2][B]
+    int32_t *heavy_n;                 // [2]
+    long long *heavy_epoch;           // [B]    step call whose heavy launch owns the environment (0: none)
     int32_t *row_state;               // [B]    what the last environment launch did with the row: 0 left untouched, 1 WRSN.step completed
                                       //        (fresh request), 2 reset / auto-reset request, 3 step still in flight, 4 terminal return
     long long *launch_t0;             // [1]    wall clock (100 MHz) at which the first wave of the current step launch started; zeroed by the
@@ -120,17 +129,22 @@ struct WrsnStepOutDev {
 };
 
 #define WRSN_LDS_SCALAR_BYTES 64
-// LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h)
-static inline int wrsn_lds_bytes(int NP, int M) {
+// nodes under charge handled by the time-parallel steady batch (more fall back to the per-second path): four up to 256 nodes -- three
+// chargers with one or two nodes in range each -- so that three environments per SIMD fit the LDS; eight up to 512, six above (three
+// environments of 1 024 nodes x 8 chargers then fit the 160 KB of a CU instead of two)
+#define WRSN_CHG_MAX(NP_) ((NP_) > 512 ? 6 : ((NP_) > 256 ? 8 : 4))
+// LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h).  `heavy`: the full variant also stages the cached receivers.
+static inline int wrsn_lds_bytes(int NP, int M, int CC, int heavy) {
     int b = 0;
-    b += 4 * NP * 8;                                  // charging rate, 2 scratch arrays, level/alive + receiver words
+    b += 3 * NP * 8 + NP * 4;                         // charging rate, 2 scratch arrays, level/alive words
+    if (heavy) b += NP * 4;                           // cached receivers
     b += M * (int)sizeof(WrsnAgent) + 2 * M * (int)sizeof(WrsnThread);
     b += (M + 1) * (8 + 8);                           // condition times / seqs
-    b += 4 * M * WRSN_CONN_CAP * 8;                   // connected-node positions (x, y), reward-entry rates and accumulators
+    b += 4 * M * CC * 8;                              // connected-node positions (x, y), reward-entry rates and accumulators
     b += 4 * 8 + WRSN_LDS_SCALAR_BYTES + 4 * 4;       // mailbox doubles, scalar bookkeeping, mailbox ints
     b += 3 * (M + 1) * 4 + 4;                         // condition agent / triggered / pending, reward-entry count
-    b += 3 * M * WRSN_CONN_CAP * 2;                   // connected-node ids, reward-entry node / charger
-    const int chg = NP > 512 ? 6 : 8;                 // WRSN_CHG_MAX(NP) of wrsn_sim.h
+    b += 3 * M * CC * 2;                              // connected-node ids, reward-entry node / charger
+    const int chg = WRSN_CHG_MAX(NP);
     b += NP * 4 + chg * 8 * 8 + chg * 64 * 8;         // steady batch: float CS, charged-node records and table
     b += (int)sizeof(WrsnEnvConst);                   // constants of the environment
     return (b + 31) & ~15;

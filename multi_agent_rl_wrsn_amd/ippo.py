@@ -219,7 +219,7 @@ class PPOLearner:
                   over the ranks with ONE all-reduce per minibatch (RCCL over xGMI with backend "nccl"; gloo in the CPU tests).
                   Parameters and BatchNorm buffers are broadcast from rank 0 at construction."""
 
-    def __init__(self, args, num_agent, map_size, device, model_path=None, infer_chunk=1024, process_group=None, inference_dtype=None):
+    def __init__(self, args, num_agent, map_size, device, model_path=None, infer_chunk=1024, process_group=None, inference_dtype=None, min_bucket=16):
         torch = _torch()
         self.torch = torch
         self.num_agent = int(num_agent)
@@ -256,25 +256,58 @@ class PPOLearner:
         self.optimizers = [torch.optim.Adam(list(self.actors[i].parameters()) + list(self.critics[i].parameters()), lr=a["lr"])
                            for i in range(self.num_agent)]
         self.infer_chunk = int(infer_chunk)
+        self.min_bucket = max(1, int(min_bucket))
 
     # -- policy ------------------------------------------------------------------------------------------------------
+    def _bucket(self, r):
+        """Rows a short inference chunk is padded to: `min_bucket` (16) doubled until it fits, at most `infer_chunk`.  MIOpen searches /
+        compiles its convolution kernels per input shape (seconds for each new one), so the forward passes of a roll-out may only
+        ever see this small set of batch shapes; padding to the power of two instead of the full chunk keeps a 20-row request
+        from paying for (and taking its BatchNorm statistics from) hundreds of copies of itself."""
+        b = self.min_bucket
+        while b < r:
+            b <<= 1
+        return min(b, self.infer_chunk)
+
     def get_action(self, agent_id, states):
-        """IPPO.py:95-105 for a batch: states [n,4,G,G] -> (action maps [n,G,G], summed log-prob [n])."""
+        """IPPO.py:95-105 for a batch: states [n,4,G,G] -> (action maps [n,G,G], summed log-prob [n]).
+
+        The actor runs in training mode like the reference's (IPPO.py never calls `.eval()`), so BatchNorm normalises with the
+        statistics of the rows in THIS forward pass: the sampled means and the stored log-probabilities depend on the batch
+        composition (rows of the chunk + its padding), exactly as the reference's depend on its batch of one."""
         torch = self.torch
         outs, lps = [], []
         with torch.no_grad():
             for s in states.split(self.infer_chunk):
-                # one batch shape for every forward pass (MIOpen searches / compiles its convolution kernels per shape: seconds for each
-                # new one): a short last chunk is filled up by repeating its own rows, whose outputs are dropped
                 r = s.shape[0]
-                if r < self.infer_chunk and self.device.type == "cuda":
-                    s = s.index_select(0, torch.arange(self.infer_chunk, device=s.device) % r)
+                nb = self._bucket(r) if self.device.type == "cuda" else r
+                if r < nb:                                    # a short chunk is filled up by repeating its own rows, whose outputs are dropped
+                    s = s.index_select(0, torch.arange(nb, device=s.device) % r)
                 mean, log_std = self._forward(self.actors[agent_id], s, inference=True)
                 mean, log_std = mean[:r].float(), log_std[:r].float()
                 dist = torch.distributions.Normal(mean, log_std.exp())
                 act = dist.sample()
                 outs.append(act); lps.append(dist.log_prob(act).sum((1, 2)))
         return torch.cat(outs), torch.cat(lps)
+
+    def rollout_logp(self, agent_id, states, actions):
+        """Log-probabilities of `actions` [n,G,G] under the current actor, evaluated over `states` in the SAME batch composition
+        `get_action` uses (same chunks, same padding, same precision): with unchanged weights this reproduces the log-probabilities
+        `get_action` returned for those rows.  `evaluate` over a different composition (a 64-row minibatch of the update) does not:
+        BatchNorm in training mode makes the actor's output a function of the whole batch -- the reference has the same property
+        (roll-out on batches of one, IPPO.py:95-105; update on minibatches, IPPO.py:236-241)."""
+        torch = self.torch
+        lps = []
+        with torch.no_grad():
+            for s, a in zip(states.split(self.infer_chunk), actions.split(self.infer_chunk)):
+                r = s.shape[0]
+                nb = self._bucket(r) if self.device.type == "cuda" else r
+                if r < nb:
+                    s = s.index_select(0, torch.arange(nb, device=s.device) % r)
+                mean, log_std = self._forward(self.actors[agent_id], s, inference=True)
+                dist = torch.distributions.Normal(mean[:r].float(), log_std[:r].float().exp())
+                lps.append(dist.log_prob(a.float()).sum((1, 2)))
+        return torch.cat(lps)
 
     def _forward(self, net, x, inference=False):
         torch = self.torch
@@ -338,10 +371,73 @@ class PPOLearner:
         for p in params:
             n = p.numel(); p.grad.copy_(flat[o:o + n].view_as(p)); o += n
 
-    def update(self, id, batch, shuffle=np.random.shuffle):
-        """IPPO.py:229-271 for charger `id`; returns the last minibatch's (pg_loss, v_loss, entropy, approx_kl, clipfrac)."""
+    def sync_buffers(self, id):
+        """Data-parallel: BatchNorm running statistics are local to a rank (every rank normalises its own minibatches); average
+        them over the ranks so that what is written to a checkpoint does not depend on which rank writes it."""
+        if self.world <= 1:
+            return
         torch = self.torch
-        nn = torch.nn
+        bufs = [b for b in list(self.actors[id].buffers()) + list(self.critics[id].buffers()) if b.dtype.is_floating_point]
+        if not bufs:
+            return
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        torch.distributed.all_reduce(flat, group=self.group)
+        flat /= self.world
+        o = 0
+        for b in bufs:
+            n = b.numel(); b.copy_(flat[o:o + n].view_as(b)); o += n
+
+    def save_checkpoint(self, id, folder):
+        """IPPO.py:296-309: `<folder>/{actor,critic}.pth`.  Under data-parallel training every rank calls this (the buffer average is
+        a collective); rank 0 alone writes."""
+        torch = self.torch
+        self.sync_buffers(id)
+        rank = torch.distributed.get_rank(self.group) if self.world > 1 else 0
+        if rank == 0:
+            os.makedirs(folder, exist_ok=True)
+            torch.save(self.actors[id].state_dict(), os.path.join(folder, "actor.pth"))
+            torch.save(self.critics[id].state_dict(), os.path.join(folder, "critic.pth"))
+
+    def minibatch_loss(self, id, batch, mb):
+        """The loss of IPPO.py:236-262 on the rows `mb` of `batch` for charger `id`: (loss, pg_loss, v_loss, entropy, approx_kl,
+        clipfrac).  Forward passes run in training mode (BatchNorm statistics of this minibatch), like the reference's."""
+        torch = self.torch
+        newlogprob, entropy = self.evaluate(id, batch["states"][mb], batch["actions"][mb])
+        newvalue = self.get_value(id, batch["states"][mb]).view(-1)
+        logratio = newlogprob - batch["log_probs"][mb]
+        ratio = logratio.exp()
+        with torch.no_grad():
+            approx_kl = ((ratio - 1) - logratio).mean()
+            clipfrac = ((ratio - 1.0).abs() > self.clip).to(ratio.dtype).mean().item()
+        adv = batch["advantages"][mb]
+        if self.norm_adv:
+            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        pg_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - self.clip, 1 + self.clip)).mean()
+        if self.clip_vloss:
+            v_un = (newvalue - batch["returns"][mb]) ** 2
+            v_cl = batch["values"][mb] + torch.clamp(newvalue - batch["values"][mb], -self.clip, self.clip)
+            v_loss = 0.5 * torch.max(v_un, (v_cl - batch["returns"][mb]) ** 2).mean()
+        else:
+            v_loss = 0.5 * ((newvalue - batch["returns"][mb]) ** 2).mean()
+        entropy_loss = entropy.mean()
+        loss = pg_loss - self.ent_coef * entropy_loss + v_loss * self.vf_coef
+        return loss, pg_loss, v_loss, entropy_loss, approx_kl, clipfrac
+
+    def apply_gradients(self, id):
+        """IPPO.py:264-268 after `loss.backward()`: (data-parallel: average the gradients over the ranks,) clip the actor's and the
+        critic's gradient norms separately, Adam step."""
+        nn = self.torch.nn
+        self._allreduce_grads(id)
+        nn.utils.clip_grad_norm_(self.actors[id].parameters(), self.max_grad_norm)
+        nn.utils.clip_grad_norm_(self.critics[id].parameters(), self.max_grad_norm)
+        self.optimizers[id].step()
+
+    def update(self, id, batch, shuffle=np.random.shuffle):
+        """IPPO.py:229-271 for charger `id`; returns the last minibatch's (pg_loss, v_loss, entropy, approx_kl, clipfrac).
+        `approx_kl` / `clipfrac` of the FIRST minibatch after a roll-out are not small, here as in the reference: the stored
+        log-probabilities were computed with the BatchNorm statistics of the roll-out batch (`get_action`; the reference: a batch of
+        one), the update recomputes them over a minibatch -- see `rollout_logp`."""
+        torch = self.torch
         b_inds = np.arange(self.batch_size)
         clipfracs = []
         stats = None
@@ -349,31 +445,11 @@ class PPOLearner:
             shuffle(b_inds)
             for start in range(0, self.batch_size, self.minibatch_size):
                 mb = torch.as_tensor(b_inds[start:start + self.minibatch_size], device=batch["states"].device, dtype=torch.long)
-                newlogprob, entropy = self.evaluate(id, batch["states"][mb], batch["actions"][mb])
-                newvalue = self.get_value(id, batch["states"][mb]).view(-1)
-                logratio = newlogprob - batch["log_probs"][mb]
-                ratio = logratio.exp()
-                with torch.no_grad():
-                    approx_kl = ((ratio - 1) - logratio).mean()
-                    clipfracs.append(((ratio - 1.0).abs() > self.clip).float().mean().item())
-                adv = batch["advantages"][mb]
-                if self.norm_adv:
-                    adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-                pg_loss = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - self.clip, 1 + self.clip)).mean()
-                if self.clip_vloss:
-                    v_un = (newvalue - batch["returns"][mb]) ** 2
-                    v_cl = batch["values"][mb] + torch.clamp(newvalue - batch["values"][mb], -self.clip, self.clip)
-                    v_loss = 0.5 * torch.max(v_un, (v_cl - batch["returns"][mb]) ** 2).mean()
-                else:
-                    v_loss = 0.5 * ((newvalue - batch["returns"][mb]) ** 2).mean()
-                entropy_loss = entropy.mean()
-                loss = pg_loss - self.ent_coef * entropy_loss + v_loss * self.vf_coef
+                loss, pg_loss, v_loss, entropy_loss, approx_kl, clipfrac = self.minibatch_loss(id, batch, mb)
+                clipfracs.append(clipfrac)
                 self.optimizers[id].zero_grad()
                 loss.backward()
-                self._allreduce_grads(id)
-                nn.utils.clip_grad_norm_(self.actors[id].parameters(), self.max_grad_norm)
-                nn.utils.clip_grad_norm_(self.critics[id].parameters(), self.max_grad_norm)
-                self.optimizers[id].step()
+                self.apply_gradients(id)
                 self.loggers[id]["losses"].append(float(loss.detach()))
                 stats = (float(pg_loss.detach()), float(v_loss.detach()), float(entropy_loss.detach()), float(approx_kl), float(np.mean(clipfracs)))
         return stats
@@ -384,9 +460,10 @@ class BatchedIPPO(PPOLearner):
     (`density_map=True` environments of runner/IPPO.py:19-21): the actor's G x G output is the action and is turned into the
     3-vector on the device (`VecWRSN.density_to_action`)."""
 
-    def __init__(self, args, env, device=None, model_path=None, capacity=None, infer_chunk=1024, process_group=None, log=None, inference_dtype=None):
+    def __init__(self, args, env, device=None, model_path=None, capacity=None, infer_chunk=1024, process_group=None, log=None, inference_dtype=None,
+                 min_bucket=16):
         super().__init__(args, env.num_agent, env.map_size, device if device is not None else env.device, model_path, infer_chunk, process_group,
-                         inference_dtype)
+                         inference_dtype, min_bucket)
         self.env = env
         self.buffers = TransitionBuffers(env, capacity or 2 * self.batch_size, env.map_size * env.map_size)
         self.timers = {"env_s": 0.0, "policy_s": 0.0, "glue_s": 0.0, "train_s": 0.0, "launches": 0, "requests": 0}
@@ -424,21 +501,36 @@ class BatchedIPPO(PPOLearner):
         tm = self.timers
         tm["policy_s"] += t1 - t0; tm["glue_s"] += (t2 - t1) + (t4 - t3); tm["env_s"] += t3 - t2; tm["launches"] += 1
         tm["requests"] += int((ids >= 0).sum())
+        self.last_ids, self.last_action3 = ids, act3          # what this launch handed to the environments (tests / logging)
         self._req = r
         return r
 
-    def roll_out(self, max_launches=100000):
+    def roll_out(self, max_launches=100000, fresh_episodes=False):
         """IPPO.py:119-210 over the batch: launches until every charger has `batch_size` transitions, then the reference's
-        per-charger batch selection.  Environments restart by auto-reset, so one roll-out spans many episodes."""
+        per-charger batch selection.  Environments restart by auto-reset, so one roll-out spans many episodes.
+
+        The environments live ACROSS roll-outs: the first call resets them, every later call goes on from the requests the
+        previous one ended with (pending actions included -- their stored log-probabilities come from the policy that chose
+        them, i.e. the one before the last update).  With a large batch the per-charger quota is reached within a few launches;
+        restarting every roll-out from `reset()` would then only ever store the first decision after the warm-up snapshot (all
+        chargers at the base station, no node death, no terminal return), which is not what the reference's roll_out collects: it
+        runs every episode to its terminal (IPPO.py:130-190).  `fresh_episodes=True` restores the restart-per-roll-out behaviour."""
         torch, env = self.torch, self.env
         if not env.auto_reset:
             raise ValueError("BatchedIPPO needs VecWRSN(auto_reset=True)")
-        self.buffers.clear()
-        self._req = env.reset()
+        if fresh_episodes or self._req is None:
+            self.buffers.clear()
+            self._req = env.reset()
+        else:
+            self.buffers.clear(keep_pending=True)
         for _ in range(max_launches):
             self.step_batch()
             if min(self.buffers.counts()) >= self.batch_size:
                 break
+        short = [a for a, n in enumerate(self.buffers.stored()) if n < self.batch_size]
+        if short:
+            raise RuntimeError("roll_out stopped after %d launches with %s transitions per charger, fewer than batch_size %d (buffer capacity %d): "
+                               "raise max_launches / capacity or lower batch_size" % (max_launches, self.buffers.stored(), self.batch_size, self.buffers.capacity))
         out = []
         for a in range(self.num_agent):
             n = self.buffers.stored()[a]
@@ -478,9 +570,6 @@ class BatchedIPPO(PPOLearner):
                 if self.log:
                     self.log(row)
                 if save_folder is not None and lg["i_so_far"] % self.save_freq == 0:      # IPPO.py:296-309 layout: <iter>/<agent>/{actor,critic}.pth
-                    folder = os.path.join(save_folder, str(lg["i_so_far"]), str(id))
-                    os.makedirs(folder, exist_ok=True)
-                    torch.save(self.actors[id].state_dict(), os.path.join(folder, "actor.pth"))
-                    torch.save(self.critics[id].state_dict(), os.path.join(folder, "critic.pth"))
+                    self.save_checkpoint(id, os.path.join(save_folder, str(lg["i_so_far"]), str(id)))
             self.timers["train_s"] += self._sync_time() - t0
         return rows

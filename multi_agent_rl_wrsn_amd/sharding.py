@@ -37,6 +37,27 @@ def init_distributed(backend=None):
     return rank, world, local_rank
 
 
+def launch_ranks(n, argv, stdout_rank0=None):
+    """One node, no launcher: start `n` rank processes of `argv` (a command line, e.g. [sys.executable, "bench.py", "--gpus", "8"])
+    with the torchrun environment -- RANK / LOCAL_RANK = 0..n-1, WORLD_SIZE = n, MASTER_ADDR 127.0.0.1, a free MASTER_PORT -- wait for
+    them and return the worst return code.  Rank 0 inherits stdout (or writes to `stdout_rank0`), the others are silenced.  Must be
+    called BEFORE the calling process touches the GPU (it only forks and waits; on this pool a process that initialised HIP must not
+    exec another program)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    procs = []
+    for r in range(int(n)):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(int(n)), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=(stdout_rank0 if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 class RolloutStats:
     """Per-environment rollout accumulators kept on the shard's device and gathered with ONE collective.
 

@@ -27,9 +27,11 @@ class VecWRSN:
     agent_type: dict / YAML path of the charger parameters (mc_types/default.yaml), None = shipped defaults
     num_agent : number of mobile chargers per environment (`num_agent`, WRSN.py:26)
     auto_reset: an environment whose last return was terminal is reset by the next `step` (status 3)
-    reuse_obs : the `state` tensor the requests return is owned by this object and must be treated as READ-ONLY (clone before modifying
-                it): map 1 of a row -- the node map, which depends on node state only -- is then not re-rendered by a step that returns at the
-                instant it was called (`wrsn_set_obs_reuse`); bit-identical results.  False re-renders every row in full.
+    reuse_obs : False (default): every returned row of `state` is rendered in full and the caller may do with the tensor what it likes.
+                True: the caller promises to treat `state` as READ-ONLY (clone before normalising / clipping in place) -- map 1 of a row,
+                the node map, which depends on node state only, is then not re-rendered by a step that returns at the instant it was
+                called (`wrsn_set_obs_reuse`, ~40 % of the random-policy benchmark's returns); bit-identical results when the promise is
+                kept, stale / corrupted map 1 when it is not.  bench.py, bench_ippo.py and the diagnostics opt in.
     step_budget: 0 = every `step` runs each WRSN.step to its end (the reference's blocking call).  > 0 bounds the work
                 of one launch per environment (units of ~400 cycles counted per simulated second / service / exact second): an
                 environment whose step is still in flight reports status 4 / agent_id -1 and simply goes on in the
@@ -41,7 +43,7 @@ class VecWRSN:
     """
 
     def __init__(self, scenarios, agent_type=None, num_agent=3, map_size=100, warm_up_time=100, device="cuda:0",
-                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0, reuse_obs=True, step_deadline_us=0):
+                 auto_reset=False, render=True, max_degree=0, max_cover=0, step_budget=0, reuse_obs=False, step_deadline_us=0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("VecWRSN needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -121,9 +123,17 @@ class VecWRSN:
         actions  : float tensor [B,3] in [0,1] (clipped inside, WRSN.py:299); density_map=False path."""
         t = self.torch
         self._bind_stream()
-        self._in_agent.copy_(agent_ids.to(device=self.device, dtype=t.int32).reshape(-1))
-        self._in_action.copy_(actions.to(device=self.device, dtype=t.float64).reshape(-1, 3))
-        self._h.step(self._in_agent.data_ptr(), self._in_action.data_ptr(), self.auto_reset, **self._out_ptrs())
+        # Arrays that already are what the C-ABI takes (int32 / float64, contiguous, on this device) go in as they are -- including this
+        # object's own `agent_id` output tensor: a launch reads row e of the inputs and writes row e of the outputs from the one block
+        # that owns environment e.  Anything else is converted into the staging buffers (two small copy kernels per call).
+        a = agent_ids
+        if not (a.dtype == t.int32 and a.device == self.device and a.is_contiguous() and a.numel() == self.num_env):
+            self._in_agent.copy_(a.to(device=self.device, dtype=t.int32).reshape(-1)); a = self._in_agent
+        x = actions
+        if not (x.dtype == t.float64 and x.device == self.device and x.is_contiguous() and x.numel() == 3 * self.num_env):
+            self._in_action.copy_(x.to(device=self.device, dtype=t.float64).reshape(-1, 3)); x = self._in_action
+        self._keep_in = (a, x)                                # alive until the launch has run
+        self._h.step(a.data_ptr(), x.data_ptr(), self.auto_reset, **self._out_ptrs())
         return self._result()
 
     def render_state(self, agent_ids, out=None):

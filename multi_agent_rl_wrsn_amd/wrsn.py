@@ -175,14 +175,17 @@ class WRSN:
                 "action": self.agents_action[aid], "reward": 0.0, "state": self.agents_prev_state[aid],
                 "terminal": terminal, "info": self._info()}
 
-    def step(self, agent_id, input_action):
+    def step(self, agent_id, input_action, _action3=None):
+        """WRSN.step (WRSN.py:289-330).  `_action3` is a test hook, not part of the reference's signature: with `density_map=True`
+        it replaces the 3-vector derived from the map (the charging spot inside the arg-max box is the one result of the path whose
+        parity is unpinned), so that a fixture recorded from the reference can be followed decision by decision."""
         t = self.vec.torch
         act3 = np.zeros(3)
         if agent_id is not None:
             action = np.array(input_action)
             self.agents_input_action[agent_id] = action.copy()
             if self.density_map:                             # WRSN.py:293-297 (normalisation included) on the device
-                action = self.density_map_to_action(action, agent_id)
+                action = self.density_map_to_action(action, agent_id) if _action3 is None else np.asarray(_action3, dtype=np.float64)
             action = np.clip(action, self.action_space.low, self.action_space.high)
             self.agents_action[agent_id] = action
             self.agents_prev_state[agent_id] = self.get_state(agent_id)     # WRSN.py:303

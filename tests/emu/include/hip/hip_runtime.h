@@ -55,6 +55,11 @@ inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }   /* kernels run at their launch call, one after another */
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 
 // ---- rendezvous primitives implemented in emu_runtime.cpp

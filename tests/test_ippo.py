@@ -170,42 +170,184 @@ def test_emulated_transition_buffers_equal_the_reference_bookkeeping():
             assert arrs["reward"][a, q] == np.float32(t[4]) and np.array_equal(arrs["next_state"][a, q], t[5])
 
 
-def _dp_worker(rank, world, port, q):
+def _flat_params(lr):
+    import torch
+    return torch.cat([p.detach().reshape(-1) for p in list(lr.actors[0].parameters()) + list(lr.critics[0].parameters())]).clone()
+
+
+def _dp_batch(seed, n, G):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return dict(states=torch.rand((n, 4, G, G), generator=g), actions=torch.randn((n, G, G), generator=g), log_probs=torch.randn(n, generator=g) - 150.0,
+                advantages=torch.randn(n, generator=g), returns=torch.randn(n, generator=g), values=torch.randn(n, generator=g))
+
+
+_DP_ARGS = dict(batch_size=8, minibatch_size=4, n_updates_per_iteration=2, lr=1e-3)
+_DP_G = 12
+
+
+def _dp_worker(rank, world, port, q, same_batch=False):
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(2)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from multi_agent_rl_wrsn_amd import PPOLearner
     torch.manual_seed(100 + rank)                              # different initial weights per rank: the broadcast must equalise them
-    G, n = 12, 8
-    lr = PPOLearner(dict(batch_size=n, minibatch_size=4, n_updates_per_iteration=2, lr=1e-3), 1, G, "cpu")
-    p0 = torch.cat([p.detach().reshape(-1) for p in list(lr.actors[0].parameters()) + list(lr.critics[0].parameters())]).clone()
-    g = torch.Generator().manual_seed(7 + rank)                # a different local batch per rank
-    batch = dict(states=torch.rand((n, 4, G, G), generator=g), actions=torch.randn((n, G, G), generator=g), log_probs=torch.randn(n, generator=g) - 150.0,
-                 advantages=torch.randn(n, generator=g), returns=torch.randn(n, generator=g), values=torch.randn(n, generator=g))
+    lr = PPOLearner(_DP_ARGS, 1, _DP_G, "cpu")
+    if rank == 0:
+        formula_fill(lr.actors[0]); formula_fill(lr.critics[0])
+        for net in (lr.actors[0], lr.critics[0]):              # what the constructor did, once more with the closed-formula weights
+            for t in list(net.parameters()) + list(net.buffers()):
+                dist.broadcast(t.data, src=0)
+    else:
+        for net in (lr.actors[0], lr.critics[0]):
+            for t in list(net.parameters()) + list(net.buffers()):
+                dist.broadcast(t.data, src=0)
+    p0 = _flat_params(lr)
+    batch = _dp_batch(7 + (0 if same_batch else rank), _DP_ARGS["batch_size"], _DP_G)   # a different local batch per rank (or the same one)
     order = np.random.RandomState(3)
     lr.update(0, batch, shuffle=order.shuffle)
-    p1 = torch.cat([p.detach().reshape(-1) for p in list(lr.actors[0].parameters()) + list(lr.critics[0].parameters())])
-    q.put((rank, p0.numpy(), p1.numpy()))
+    q.put((rank, p0.numpy(), _flat_params(lr).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradient_exchange_gloo_world2():
-    """f4: after the rank-0 broadcast and two epochs of minibatch updates with ONE all-reduce of the flattened actor + critic
-    gradients per minibatch, both ranks hold identical parameters (they saw different batches), and the parameters moved."""
+def _run_world2(same_batch):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, same_batch)) for r in range(2)]
     for p in ps: p.start()
     res = sorted([q.get(timeout=300) for _ in ps], key=lambda t: t[0])
     for p in ps: p.join(timeout=60)
     assert all(p.exitcode == 0 for p in ps)
-    (_, a0, a1), (_, b0, b1) = res
-    assert np.array_equal(a0, b0)                                # broadcast from rank 0
-    assert np.array_equal(a1, b1)                                # identical updates on both ranks
-    assert np.abs(a1 - a0).max() > 1e-5
+    return res
+
+
+def _single_process_reference(batches):
+    """What the data-parallel update has to equal: ONE process, the same initial weights, and per minibatch the gradient that is the
+    mean of the ranks' gradients -- computed here by hand from one backward pass per rank batch (IPPO.py:225-271 otherwise unchanged:
+    the two clip_grad_norm_ calls and the Adam step act on the averaged gradient)."""
+    import torch
+    from multi_agent_rl_wrsn_amd import PPOLearner
+    torch.set_num_threads(2)
+    lr = PPOLearner(_DP_ARGS, 1, _DP_G, "cpu")
+    formula_fill(lr.actors[0]); formula_fill(lr.critics[0])
+    p0 = _flat_params(lr)
+    params = list(lr.actors[0].parameters()) + list(lr.critics[0].parameters())
+    order = np.random.RandomState(3)
+    b_inds = np.arange(lr.batch_size)
+    for _ in range(lr.n_updates_per_iteration):
+        order.shuffle(b_inds)
+        for start in range(0, lr.batch_size, lr.minibatch_size):
+            mb = torch.as_tensor(b_inds[start:start + lr.minibatch_size], dtype=torch.long)
+            grads = []
+            for batch in batches:
+                lr.optimizers[0].zero_grad()
+                lr.minibatch_loss(0, batch, mb)[0].backward()
+                grads.append([p.grad.detach().clone() for p in params])
+            for k, p in enumerate(params):
+                acc = grads[0][k].clone()
+                for g in grads[1:]:
+                    acc += g[k]                                # the all-reduce sums ...
+                p.grad.copy_(acc / len(grads))                 # ... and the bucket is divided by the world size
+            lr.world = 1                                       # (no process group here: apply_gradients must not try to all-reduce)
+            lr.apply_gradients(0)
+    return p0.numpy(), _flat_params(lr).numpy()
+
+
+def test_data_parallel_update_equals_the_single_process_update_of_the_mean_gradient_gloo_world2():
+    """f4: two ranks with DIFFERENT local batches, one all-reduce of the flattened actor + critic gradients per minibatch == a
+    single-process update whose gradient is the mean of the two ranks' gradients (computed by hand from two backward passes).  A wrong
+    exchange (sum instead of mean, a stale or partial bucket, only one of the two networks) moves the parameters elsewhere: the first
+    Adam step is lr * g / (|g| + eps), the clipping thresholds see the gradient norm, and four steps compound it."""
+    (_, a0, a1), (_, b0, b1) = _run_world2(same_batch=False)
+    assert np.array_equal(a0, b0) and np.array_equal(a1, b1)    # broadcast from rank 0; identical updates on both ranks
+    r0, r1 = _single_process_reference([_dp_batch(7, 8, _DP_G), _dp_batch(8, 8, _DP_G)])
+    assert np.array_equal(r0, a0)
+    assert np.abs(a1 - a0).max() > 1e-4                          # four Adam steps of lr 1e-3
+    # gloo sums the two float32 buckets in the order the by-hand reference does: bit-equal here; a few ulps would still pass
+    assert np.allclose(a1, r1, rtol=0, atol=2e-7), np.abs(a1 - r1).max()
+    # and it is NOT what a rank does on its own batch alone, nor with the summed (un-averaged) gradient
+    alone0, alone1 = _single_process_reference([_dp_batch(7, 8, _DP_G)])
+    assert np.abs(alone1 - a1).max() > 1e-4
+
+
+def test_data_parallel_update_with_the_same_batch_equals_world1_bit_for_bit():
+    """f4: both ranks hold the SAME batch -> the averaged gradient (g + g) / 2 is g exactly, and the world-2 update is the world-1
+    update bit for bit."""
+    (_, a0, a1), (_, b0, b1) = _run_world2(same_batch=True)
+    r0, r1 = _single_process_reference([_dp_batch(7, 8, _DP_G)])
+    assert np.array_equal(a0, r0) and np.array_equal(a1, b1)
+    assert np.array_equal(a1, r1)
+
+
+def test_rollout_logp_reproduces_the_stored_log_probabilities_in_the_same_batch_composition():
+    """The invariant behind the large first-minibatch approx_kl of a roll-out: with frozen weights, the log-probability of a stored
+    action evaluated over the SAME batch the roll-out forward saw is the stored one; over another composition (a minibatch of the
+    update) it is not, because the actor runs BatchNorm in training mode (IPPO.py:95-113 has the same property with its batch of one)."""
+    import torch
+    from multi_agent_rl_wrsn_amd import PPOLearner
+    torch.manual_seed(0); torch.set_num_threads(2)
+    G, n = 12, 10
+    lr = PPOLearner(dict(batch_size=8, minibatch_size=4), 1, G, "cpu", infer_chunk=4)
+    formula_fill(lr.actors[0])
+    states = torch.rand((n, 4, G, G))
+    act, lp = lr.get_action(0, states)                          # chunks of 4, 4, 2 rows
+    assert torch.allclose(lr.rollout_logp(0, states, act), lp, rtol=1e-6, atol=1e-4)
+    with torch.no_grad():
+        other, _ = lr.evaluate(0, states, act)                  # one batch of 10 rows: different BatchNorm statistics
+    assert (other - lp).abs().max() > 1e-2
+
+
+def _rank_probe(path):
+    return "import os; open(os.path.join(%r, os.environ['RANK']), 'w').write(' '.join(os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))" % path
+
+
+def test_launch_ranks_sets_the_torchrun_environment_for_every_child(tmp_path):
+    """bench.py / bench_ippo.py `--gpus N` without a launcher: N children with RANK / LOCAL_RANK 0..N-1, WORLD_SIZE N, one common
+    MASTER_ADDR / MASTER_PORT; the worst return code comes back."""
+    import sys
+    from multi_agent_rl_wrsn_amd import launch_ranks
+    rc = launch_ranks(3, [sys.executable, "-c", _rank_probe(str(tmp_path))])
+    assert rc == 0
+    rows = [open(os.path.join(str(tmp_path), str(r))).read().split() for r in range(3)]
+    assert [r[0] for r in rows] == ["0", "1", "2"] and [r[1] for r in rows] == ["0", "1", "2"] and all(r[2] == "3" for r in rows)
+    assert all(r[3] == "127.0.0.1" for r in rows) and len({r[4] for r in rows}) == 1 and int(rows[0][4]) > 0
+    assert launch_ranks(2, [sys.executable, "-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"]) == 3
+
+
+def test_bench_scripts_start_their_ranks_before_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` / `python bench_ippo.py --gpus 2` with WORLD_SIZE unset hand over to launch_ranks before torch is
+    imported (the children here are stubbed by pointing sys.executable's script at a probe through PYTHONSTARTUP-free means: the
+    scripts are imported as modules and `launch_ranks` is replaced)."""
+    import importlib.util
+    import sys
+    import multi_agent_rl_wrsn_amd.sharding as sharding
+    calls = []
+    real = sharding.launch_ranks
+    sharding.launch_ranks = lambda n, argv, **kw: calls.append((n, list(argv))) or 0
+    env_backup = os.environ.pop("WORLD_SIZE", None)
+    try:
+        for script in ("bench.py", "bench_ippo.py"):
+            spec = importlib.util.spec_from_file_location("probe_" + script[:-3], os.path.join(ROOT, script))
+            mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+            argv = sys.argv; sys.argv = [script, "--gpus", "2"]
+            had_torch_cuda_init = "torch" in sys.modules and sys.modules["torch"].cuda.is_initialized()
+            try:
+                with pytest.raises(SystemExit) as ex:
+                    mod.main()
+            finally:
+                sys.argv = argv
+            assert ex.value.code == 0
+            assert calls[-1][0] == 2 and calls[-1][1][-2:] == ["--gpus", "2"] and calls[-1][1][1].endswith(script)
+            if "torch" in sys.modules:
+                assert sys.modules["torch"].cuda.is_initialized() == had_torch_cuda_init
+    finally:
+        sharding.launch_ranks = real
+        if env_backup is not None:
+            os.environ["WORLD_SIZE"] = env_backup

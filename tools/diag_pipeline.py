@@ -20,7 +20,7 @@ streams = [torch.cuda.Stream(dev) for _ in range(G)]
 envs, gens, reqs, acts = [], [], [], []
 for g in range(G):
     with torch.cuda.stream(streams[g]):
-        envs.append(VecWRSN(scs[g * per:(g + 1) * per], None, 3, device=str(dev), auto_reset=True, step_budget=budget))
+        envs.append(VecWRSN(scs[g * per:(g + 1) * per], None, 3, device=str(dev), auto_reset=True, step_budget=budget, reuse_obs=True))
         gens.append(torch.Generator(device=dev).manual_seed(7 + g))
         reqs.append(envs[g].reset())
         acts.append(torch.rand((steps + 20, per, 3), generator=gens[g], device=dev, dtype=torch.float64))

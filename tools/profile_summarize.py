@@ -21,6 +21,14 @@ def pmc(sub, name):
         if k is None or int(r["Grid_Size"]) < min_grid: continue          # the bench launches only (4096 environments)
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
     return agg
+# average duration per kernel from the --kernel-trace --stats pass (the lean / full instantiations of the step kernel listed separately)
+dur = {}
+if st:
+    for r in csv.DictReader(open(st[0])):
+        for k in ("wrsn_step_kernel", "wrsn_obs_kernel", "wrsn_sort_kernel", "wrsn_estimate_kernel"):
+            if k in r["Name"]:
+                key = k + ("<lean>" if ", false>" in r["Name"] else ("<full>" if ", true>" in r["Name"] else ""))
+                dur[key] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
 fe, wr = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md HBM section) of "
                "`python3 bench.py --steps 40 --warmup 10 --cpu-seconds 0 --kernel-steps 5 --no-blocking-run` (default step budget); counters are KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
@@ -29,5 +37,9 @@ for k in ("wrsn_step_kernel", "wrsn_obs_kernel"):
     if fe[k][1] and wr[k][1]:
         f = fe[k][0] / fe[k][1]; w = wr[k][0] / wr[k][1]
         res["kernels"][k] = {"fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "hbm_bytes_per_launch": (2 * f + w) * 1024, "dispatches": fe[k][1]}
+        cand = [v for kk, v in dur.items() if kk.startswith(k)]
+        if cand:                                                # the instantiation with the most calls is the one of the bench loop
+            res["kernels"][k]["rocprof_avg_us"] = max(cand, key=lambda v: v["calls"])["avg_us"]
+res["kernel_durations"] = dur
 json.dump(res, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1)
 print(json.dumps(res["kernels"], indent=1))

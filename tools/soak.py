@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 import torch
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 B = int(os.environ.get("WRSN_B", "4096")); K = int(os.environ.get("WRSN_K", "3000")); budget = int(os.environ.get("WRSN_BUDGET", "1250"))
-env = VecWRSN([synth_scenario(7000 + e, 200, 200) for e in range(B)], None, 3, auto_reset=True, step_budget=budget, step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")))
+env = VecWRSN([synth_scenario(7000 + e, 200, 200) for e in range(B)], None, 3, auto_reset=True, step_budget=budget, step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")), reuse_obs=True)
 g = torch.Generator(device="cuda").manual_seed(11)
 r = env.reset()
 bad = torch.zeros((), dtype=torch.int64, device="cuda"); nan = torch.zeros((), dtype=torch.int64, device="cuda")
