@@ -76,7 +76,7 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     from multi_agent_rl_wrsn_amd import RolloutStats, VecWRSN
     B = len(scenarios)
     t_set = time.time()
-    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget, step_deadline_us=(deadline_us if budget > 0 else 0),
+    env = VecWRSN(scenarios, None, M, map_size=G, device=str(dev), auto_reset=True, step_budget=budget, step_deadline_us=deadline_us,
                   reuse_obs=True)                             # the random policy never writes into the state tensor
     env.synchronize()
     t_set = time.time() - t_set

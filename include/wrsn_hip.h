@@ -147,12 +147,18 @@ int wrsn_step(wrsn_t *h, const int32_t *agent_id, const double *action, int32_t 
  * suspension may split a closed-form jump / a batch of the float32 priority pipeline in two); only the launch it is reported in changes. */
 int wrsn_set_step_budget(wrsn_t *h, int32_t work_units);
 
-/* On top of a step budget: a common DEADLINE for the waves of a launch, in microseconds after its first wave started
- * (0, the default: none).  An environment whose step is still running at the deadline stops at the next grid-item boundary
- * exactly as if its work budget were used up (status 4, the next wrsn_step goes on with it); every environment still
- * advances by at least one item per launch.  A wave that starts late thus gets what is left of the launch instead of a
- * full budget, and the launch ends with (nearly) all wave slots busy.  The requests are the same as ever; WHICH launch
- * reports a request now depends on timing (the work budget alone is deterministic).  Needs wrsn_set_step_budget > 0. */
+/* TIME-SLICED launches: a common deadline for the waves of a wrsn_step launch, in microseconds after it started (0, the default:
+ * none).  The launch walks the environments in a cyclic order that starts where the previous launch stopped; a wave runs its
+ * environment's WRSN.step until it returns or the deadline passes -- then it stops at the next grid-item boundary exactly as if a work
+ * budget were used up (status 4 / agent_id -1; the next wrsn_step goes on with it) -- and a wave that would only start when the slice is
+ * (nearly) over does not touch its environment at all: the action given for that row is kept in the environment's latch, the row
+ * reports status 4 like a step in flight, and the next launches take it up (the caller passes -1 / anything for a status-4 row, as with
+ * a step budget; -2 still leaves a row untouched for one call, a reset drops a latched action).  Every environment a launch takes
+ * advances by at least one item, a packet-exact second is not begun in the last ~60 us of a slice.  The wave slots stay busy for the
+ * whole slice -- with one work cap per environment a quarter of the slot time of a launch is idle while the capped waves finish -- and
+ * no launch-order kernels are needed.  The requests are the same as ever (tests: agent, time, terminal identical, rewards to ~1e-9);
+ * WHICH launch reports a request depends on timing (the work budget alone is deterministic).  A step budget, if set, still caps what one
+ * visit may spend. */
 int wrsn_set_step_deadline(wrsn_t *h, int32_t microseconds);
 
 /* WRSN.density_map_to_action (WRSN.py:229-287) with the normalisation of WRSN.step (WRSN.py:293-296), for the

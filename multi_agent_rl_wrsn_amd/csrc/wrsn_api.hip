@@ -152,7 +152,8 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     dim3 grid(nenv), block(64);
     long long epoch = 0;
     if (mode == WRSN_MODE_STEP) epoch = ++h->epoch;            // every step call: a hand-off stamp names the one call whose heavy launch owns the environment
-    const bool split = budget > 0 && h->split && h->ev2_ok;
+    const bool queue = (mode == WRSN_MODE_STEP) && h->deadline_ticks > 0;    // work-queue launch (wrsn_set_step_deadline)
+    const bool split = !queue && budget > 0 && h->split && h->ev2_ok;
     const bool timed = (mode == WRSN_MODE_STEP) && h->timing && h->ev_ok;
     if (timed) (void)hipEventRecord(h->ev[0], h->stream);
     // A budgeted step call is two launches side by side.  On the second stream: the full variant of the step kernel over the environments the
@@ -169,6 +170,20 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     }
 #undef WRSN_HEAVY
     const int next_list = split ? (int)((epoch + 1) & 1) : -1;
+    if (queue) {
+        // latch + preset kernel, then one block per environment in this launch's cyclic order: the blocks that only start when the time slice
+        // is over leave their environments alone
+        hipLaunchKernelGGL(wrsn_latch_kernel, dim3((nenv + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, out);
+        if (timed) (void)hipEventRecord(h->ev[1], h->stream);
+        const int qbudget = budget > 0 ? budget : (1 << 28);   // the deadline is looked at wherever a work budget is
+#define WRSN_QUEUE(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, 0, agent_id, action, \
+                                           auto_reset, qbudget, epoch, 0, mask, out, 3, h->deadline_ticks)
+        WRSN_NPL_SWITCH(h->npl, WRSN_QUEUE, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
+#undef WRSN_QUEUE
+        if (timed) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; h->ev_rec = 1; }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
         hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2,
@@ -320,6 +335,8 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
         if ((rc = dalloc(h, &d.heavy_n, 2))) break;
         if ((rc = dalloc(h, &d.heavy_epoch, B))) break;
+        if ((rc = dalloc(h, &d.queue, 8 + 64))) break;
+        if ((rc = dalloc(h, &d.qskip, B))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
     } while (0);
     if (rc) { wrsn_destroy(h); return rc; }
@@ -479,7 +496,6 @@ int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
 
 int wrsn_set_step_deadline(wrsn_t* h, int32_t microseconds) {
     if (!h || microseconds < 0 || microseconds > 10000000) return fail(WRSN_ERR_ARG, "bad step deadline");
-    if (microseconds > 0 && h->bp2 == 0) return fail(WRSN_ERR_STATE, "the launch deadline needs the device-side launch order (at most 8192 environments per handle)");
     h->deadline_ticks = microseconds * 100;                    // wall_clock64 counts at 100 MHz
     return WRSN_OK;
 }

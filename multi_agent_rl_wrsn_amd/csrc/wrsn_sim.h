@@ -72,6 +72,18 @@
 #endif
 // profile slots: 0 scalar_run  1 grid_run  2 node_half(fast)  3 update_reward  4 exact_walk  5 rebuild_cache  6 set_levels
 //                7 min_fitness 8 precheck  9 conn_build  10 load  11 store  12 #services  13 #fused seconds  14 #jumped seconds  15 #generic items
+// time-sliced launches (100 MHz ticks): a block that starts less than WRSN_PULL_MARGIN before the deadline does not take its environment (a
+// visit costs a load and a store whatever it achieves); a packet-exact second (~70 us) is not begun less than WRSN_EXACT_MARGIN before it,
+// unless it is the first item of the visit (every environment a launch takes advances)
+#ifndef WRSN_PULL_MARGIN
+#define WRSN_PULL_MARGIN 3000
+#endif
+#ifndef WRSN_TICKS_PER_FUSED_SECOND
+#define WRSN_TICKS_PER_FUSED_SECOND 35       // what a second of the time-parallel steady path takes (0.35 us), for the clamp of a fused run to the time left
+#endif
+#ifndef WRSN_EXACT_MARGIN
+#define WRSN_EXACT_MARGIN 6000
+#endif
 #define WRSN_URGENT 0
 #define WRSN_NORMAL 1
 #define WRSN_INF (__builtin_inf())
@@ -198,6 +210,25 @@ WDEV int64_t wu(int64_t v) {
     return ((int64_t)hi << 32) | (int64_t)lo;
 }
 
+// ------------------------------------------------------------------ global address space
+// A pointer the kernel loads from its descriptor (WrsnDev) is a flat pointer to the compiler: every access through it is a flat_load that
+// also counts against the LDS queue.  The arrays of a handle live in HBM: say so, and the access is a global_load with a scalar base.
+#ifndef WRSN_GLOBAL_AS
+#define WRSN_GLOBAL_AS __attribute__((address_space(1)))
+#endif
+template <typename T> WDEV const T WRSN_GLOBAL_AS* wrsn_global(const T* p) { return (const T WRSN_GLOBAL_AS*)p; }
+template <typename T> WDEV T WRSN_GLOBAL_AS* wrsn_global(T* p) { return (T WRSN_GLOBAL_AS*)p; }
+
+// 16-byte rows of the packed static tables (eight 16-bit node ids): one dwordx4 load from the global address space
+struct alignas(16) WrsnU4 { uint32_t x, y, z, w; };
+#ifndef WRSN_LD_U4_DEFINED
+WDEV WrsnU4 wrsn_ld_u4(const WrsnU4 WRSN_GLOBAL_AS* p) {
+    typedef uint32_t v4_ __attribute__((ext_vector_type(4)));
+    const v4_ t = *(const v4_ WRSN_GLOBAL_AS*)p;
+    WrsnU4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r;
+}
+#endif
+
 // ------------------------------------------------------------------ LDS gathers
 // Eight data-dependent LDS words in ONE round trip: the ds_read are issued back to back and waited for once.  Written
 // as inline assembly because the register-pressure heuristics of the scheduler otherwise emit read / wait / use eight
@@ -253,12 +284,15 @@ struct Sim {
     int dirty;                                               // which state arrays differ from HBM: 1 routing (d1, d2, rcv), 2 level/alive words, 4 CS
     int work, budget;                                        // work units spent in this launch / allowed (0 = unlimited); wave-uniform
     long long t_deadline;                                    // wall clock at which this launch stops taking new grid items (0 = none); wave-uniform
+    long long t_exact;                                       // ... at which it stops beginning packet-exact seconds (time-sliced launches; 0 = none)
     int fit_dirty, map1_valid;                               // a grid service ran since last_minfit was evaluated / map 1 of the observation still stands (wave-uniform)
-    int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has
+    int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has; full variant: a
+                                                             // packet-exact second was put off because the time-sliced launch is about to end
+    int n_items;                                             // grid items completed in this visit (wave-uniform)
     double last_minfit;
     WRSN_PROF_DECL
 
-    struct alignas(16) U4 { uint32_t x, y, z, w; };
+    using U4 = WrsnU4;
     static constexpr int kChgMax = WRSN_CHG_MAX(64 * NPL);
     // lane-0 bookkeeping of the scalar event processor lives in LDS, not in registers
     struct Scalar { double ev_time, ev2_time; int64_t ev_seq, n_events; int32_t L, pend, pend_idx, ev_valid, ev_kind, ev_idx, ev_prio, ev_uf; };
@@ -268,23 +302,23 @@ struct Sim {
     // per-environment constants are staged in LDS by bind(): a plain global load of them costs a full memory round
     // trip (the backend cannot use scalar loads on mutable global memory)
     WDEV const WrsnEnvConst* EC() const { return (const WrsnEnvConst*)(SS() + 1); }
-    WDEV const double* NX() const { return dp->node_x + (size_t)env * NP; }
-    WDEV const double* NY() const { return dp->node_y + (size_t)env * NP; }
-    WDEV const double* DBS() const { return dp->dist_bs + (size_t)env * NP; }
-    WDEV const int32_t* NB_OFF() const { return dp->nb_off + (size_t)env * (NP + 1); }
-    WDEV const int32_t* NB_IDX() const { return dp->nb_idx + (size_t)env * dp->ECAP; }
-    WDEV const double* NB_DIST() const { return dp->nb_dist + (size_t)env * dp->ECAP; }
-    WDEV const int32_t* TC_OFF() const { return dp->tc_off + (size_t)env * (dp->TP + 1); }
-    WDEV const int32_t* TC_IDX() const { return dp->tc_idx + (size_t)env * dp->CCAP; }
-    WDEV const int32_t* NCOV() const { return dp->ncov + (size_t)env * NP; }
-    WDEV const int32_t* NFLAGS() const { return dp->nflags + (size_t)env * NP; }   // bit 0 direct node, bit 1 more than 8 neighbours, bits 8.. len(listTargets)
-    WDEV const U4* NBP() const { return (const U4*)(dp->nbp + (size_t)env * NP * 4); }
-    WDEV const double* NBP_ES() const { return dp->nbp_es + (size_t)env * NP * 8; }
-    WDEV const double* ES_BS() const { return dp->es_bs + (size_t)env * NP; }
-    WDEV const U4* ADJM() const { return (const U4*)(dp->adjm + (size_t)env * NP * 8); }   // [NP][4] uint64 neighbourhood masks (nodes 0..255)
-    WDEV const U4* TCP() const { return (const U4*)(dp->tcp + (size_t)env * dp->TP * 4); }
-    WDEV double* RING() const { return (use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP; }
-    WDEV double* LOGBUF() const { return (use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP; }
+    WDEV const double WRSN_GLOBAL_AS* NX() const { return wrsn_global(dp->node_x + (size_t)env * NP); }
+    WDEV const double WRSN_GLOBAL_AS* NY() const { return wrsn_global(dp->node_y + (size_t)env * NP); }
+    WDEV const double WRSN_GLOBAL_AS* DBS() const { return wrsn_global(dp->dist_bs + (size_t)env * NP); }
+    WDEV const int32_t WRSN_GLOBAL_AS* NB_OFF() const { return wrsn_global(dp->nb_off + (size_t)env * (NP + 1)); }
+    WDEV const int32_t WRSN_GLOBAL_AS* NB_IDX() const { return wrsn_global(dp->nb_idx + (size_t)env * dp->ECAP); }
+    WDEV const double WRSN_GLOBAL_AS* NB_DIST() const { return wrsn_global(dp->nb_dist + (size_t)env * dp->ECAP); }
+    WDEV const int32_t WRSN_GLOBAL_AS* TC_OFF() const { return wrsn_global(dp->tc_off + (size_t)env * (dp->TP + 1)); }
+    WDEV const int32_t WRSN_GLOBAL_AS* TC_IDX() const { return wrsn_global(dp->tc_idx + (size_t)env * dp->CCAP); }
+    WDEV const int32_t WRSN_GLOBAL_AS* NCOV() const { return wrsn_global(dp->ncov + (size_t)env * NP); }
+    WDEV const int32_t WRSN_GLOBAL_AS* NFLAGS() const { return wrsn_global(dp->nflags + (size_t)env * NP); }   // bit 0 direct node, bit 1 more than 8 neighbours, bits 8.. len(listTargets)
+    WDEV const U4 WRSN_GLOBAL_AS* NBP() const { return wrsn_global((const U4*)(dp->nbp + (size_t)env * NP * 4)); }
+    WDEV const double WRSN_GLOBAL_AS* NBP_ES() const { return wrsn_global(dp->nbp_es + (size_t)env * NP * 8); }
+    WDEV const double WRSN_GLOBAL_AS* ES_BS() const { return wrsn_global(dp->es_bs + (size_t)env * NP); }
+    WDEV const U4 WRSN_GLOBAL_AS* ADJM() const { return wrsn_global((const U4*)(dp->adjm + (size_t)env * NP * 8)); }   // [NP][4] uint64 neighbourhood masks (nodes 0..255)
+    WDEV const U4 WRSN_GLOBAL_AS* TCP() const { return wrsn_global((const U4*)(dp->tcp + (size_t)env * dp->TP * 4)); }
+    WDEV double WRSN_GLOBAL_AS* RING() const { return wrsn_global((use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP); }
+    WDEV double WRSN_GLOBAL_AS* LOGBUF() const { return wrsn_global((use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP); }
     // ---- LDS carve-up (must match wrsn_lds_bytes).  The lean variant never touches the cached receivers: they stay in HBM.
     WDEV double* SRR() const { return smem_; }
     WDEV double* SU() const { return smem_ + NP; }
@@ -325,7 +359,7 @@ struct Sim {
         cap = wu(EC()->capacity); thr = wu(EC()->threshold); max_time = wu(EC()->max_time);
         inv_a_b2 = wu((EC()->beta * EC()->beta) / EC()->alpha);
         teps = wu(1e-9 * cap);
-        err = 0; deaths_flag = 0; need_heavy = 0; t_deadline = 0;
+        err = 0; deaths_flag = 0; need_heavy = 0; t_deadline = 0; t_exact = 0;
         if (lane == 0) { Scalar* q = SS(); q->pend = 0; q->pend_idx = 0; q->L = 0; q->ev_valid = 0; q->n_events = 0; }
     }
 
@@ -346,7 +380,7 @@ struct Sim {
             nb.direct |= (unsigned)(f & 1) << j; nb.ncov[j] = f >> 8;
             nb.ovf |= (unsigned)((f >> 1) & 1) << j;
             if (kNbReg) {
-                const U4 v = NBP()[i];
+                const U4 v = wrsn_ld_u4(NBP() + (i));
                 nb.p[kNbReg ? j : 0][0] = v.x; nb.p[kNbReg ? j : 0][1] = v.y; nb.p[kNbReg ? j : 0][2] = v.z; nb.p[kNbReg ? j : 0][3] = v.w;
             }
         }
@@ -356,7 +390,7 @@ struct Sim {
     static constexpr int kNbGrp = kNbReg ? 1 : 4;
     WDEV U4 nb_words(const NbRegs& nb, int j) const {
         if (kNbReg) { U4 v; v.x = nb.p[kNbReg ? j : 0][0]; v.y = nb.p[kNbReg ? j : 0][1]; v.z = nb.p[kNbReg ? j : 0][2]; v.w = nb.p[kNbReg ? j : 0][3]; return v; }
-        return NBP()[j * 64 + lane];
+        return wrsn_ld_u4(NBP() + (j * 64 + lane));
     }
     // eight packed ids -> indices (`self` where the slot is empty) and a validity mask
     WDEV static unsigned unpack8(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int self, int (&idx)[8]) {
@@ -371,13 +405,13 @@ struct Sim {
     }
     // neighbours of node i beyond the packed ones / for NPL > 6: the sorted CSR list
 #define WRSN_FOR_NEIGHBORS_CSR(i, nbvar, body)                                                     \
-    { const int32_t* off_ = NB_OFF(); const int32_t* idx_ = NB_IDX();                              \
+    { const auto off_ = NB_OFF(); const auto idx_ = NB_IDX();                              \
       for (int p_ = off_[i]; p_ < off_[(i) + 1]; ++p_) { const int nbvar = idx_[p_]; body } }
 
     // nodes covering target t: the first eight ids are packed like the neighbour ids (0xFFFE in the last slot: more
     // than eight, walk the CSR list).  Returns the validity mask, 0xFFFFFFFF for "use the CSR list".
     WDEV unsigned covering8(int t, int (&idx)[8]) const {
-        const U4 v = TCP()[t];
+        const U4 v = wrsn_ld_u4(TCP() + (t));
         if ((v.w >> 16) == 0xFFFEu) return 0xFFFFFFFFu;
         return unpack8(v.x, v.y, v.z, v.w, 0, idx);
     }
@@ -408,20 +442,41 @@ struct Sim {
     }
 
     // -------------------------------------------------------------- state load / store
+    // Everything an environment keeps in HBM between two launches comes in with ONE memory round trip: all loads are issued first
+    // (global address space, clamped indices instead of predicated loads -- a load behind a branch is a round trip of its own), then the
+    // LDS is filled.  r02 took ~30 dependent round trips here (19 K cycles per environment and launch).
     WDEV void load(const WrsnNodeArrays& a) { WRSN_PROF_T0
-        size_t nb = (size_t)env * NP;
+        const size_t nb = (size_t)env * NP;
         am = 0; dirty = 0;
+        const auto gE = wrsn_global(a.E + nb), gCS = wrsn_global(a.CS + nb), gd1 = wrsn_global(a.d1 + nb), gd2 = wrsn_global(a.d2 + nb), gRR = wrsn_global(a.RR + nb);
+        const auto gls = wrsn_global(a.ls + nb), grcv = wrsn_global(a.rcv + nb);
+        double rr[NPL]; int lsw[NPL], rcw[NPL];
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-            int i = j * 64 + lane;
-            const bool real = i < N;                       // the padding up to NP is never read nor written back
-            E[j] = real ? a.E[nb + i] : 0.0; CS[j] = real ? a.CS[nb + i] : 0.0; d1[j] = real ? a.d1[nb + i] : 0.0; d2[j] = real ? a.d2[nb + i] : 0.0;
-            SRR()[i] = real ? a.RR[nb + i] : 0.0;
-            int ls = real ? a.ls[nb + i] : 0; SLS()[i] = ls;
-            if constexpr (HEAVY) SRCV()[i] = real ? a.rcv[nb + i] : -1;
-            am |= (unsigned)(ls & 1) << j;
+            const int i = j * 64 + lane, ii = i < N ? i : 0;   // the padding up to NP is never read nor written back
+            E[j] = gE[ii]; CS[j] = gCS[ii]; d1[j] = gd1[ii]; d2[j] = gd2[ii]; rr[j] = gRR[ii]; lsw[j] = gls[ii];
+            rcw[j] = HEAVY ? grcv[ii] : -1;
         }
         const WrsnEnvDyn* dy = a.dyn + env;
+        // charger / process records and connected-node lists: lane w takes 8-byte word w, w + 64, ... (fixed trip counts for the largest
+        // configuration, clamped indices)
+        constexpr int kAgW = (int)(sizeof(WrsnAgent) / 8), kThW = (int)(sizeof(WrsnThread) / 8);
+        constexpr int kAgT = (WRSN_MAX_MC * kAgW + 63) / 64, kThT = (WRSN_MAX_TH * kThW + 63) / 64, kCnT = (WRSN_MAX_MC * WRSN_CONN_CAP + 63) / 64;
+        const int nag = M * kAgW, nth = 2 * M * kThW, ncn = M * CC;
+        const auto ga = wrsn_global((const uint64_t*)dy->ag), gt = wrsn_global((const uint64_t*)dy->th);
+        const auto gc = wrsn_global(a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP);
+        const auto gr = wrsn_global(a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2);
+        uint64_t va[kAgT], vt[kThT]; int16_t vc[kCnT]; double vx[kCnT], vy[kCnT];
+#pragma unroll
+        for (int k = 0; k < kAgT; ++k) { const int w = lane + 64 * k; va[k] = ga[w < nag ? w : 0]; }
+#pragma unroll
+        for (int k = 0; k < kThT; ++k) { const int w = lane + 64 * k; vt[k] = gt[w < nth ? w : 0]; }
+#pragma unroll
+        for (int k = 0; k < kCnT; ++k) {                      // list m at stride WRSN_CONN_CAP in HBM, CC in LDS
+            const int w = lane + 64 * k, wc = w < ncn ? w : 0;
+            const int g = (wc / CC) * WRSN_CONN_CAP + (wc % CC);
+            vc[k] = gc[g]; vx[k] = gr[2 * g]; vy[k] = gr[2 * g + 1];
+        }
         now = wu(dy->now); seq = wu(dy->seq); net_time = wu(dy->net_time); net_seq = wu(dy->net_seq); ur_time = wu(dy->ur_time); ur_seq = wu(dy->ur_seq);
         node_time = wu(dy->node_time); node_seq = wu(dy->node_seq); last_minfit = wu(dy->last_minfit); opmax = wu(dy->opmax);
         n_ticks = wu(dy->n_ticks); n_exact = wu(dy->n_exact);
@@ -429,41 +484,51 @@ struct Sim {
         levels_dirty = wu(dy->levels_dirty); cache_dirty = wu(dy->cache_dirty); irreg = wu(dy->irreg); ring_len = wu(dy->ring_len);
         ring_head = wu(dy->ring_head); safe_ticks = wu(dy->safe_ticks); frozen = wu(dy->frozen);
         log_pending = wu(dy->log_pending); fit_dirty = wu(dy->fit_dirty); map1_valid = wu(dy->map1_valid);
-        const uint64_t* ga = (const uint64_t*)dy->ag; uint64_t* la = (uint64_t*)SAG();
-        for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) la[w] = ga[w];
-        const uint64_t* gt = (const uint64_t*)dy->th; uint64_t* lt = (uint64_t*)STH();
-        for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) lt[w] = gt[w];
-        const int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        const double* gr = a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2;
-        for (int w = lane; w < M * CC; w += 64) {             // list m at stride WRSN_CONN_CAP in HBM, CC in LDS
-            const int g = (w / CC) * WRSN_CONN_CAP + (w % CC);
-            SCONN()[w] = gc[g]; SCONNXY()[2 * w] = gr[2 * g]; SCONNXY()[2 * w + 1] = gr[2 * g + 1];
+        const int n_conn0 = dy->n_connected; const int64_t n_ev0 = dy->n_events;
+        // ---- everything is on its way: fill the LDS
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int i = j * 64 + lane; const bool real = i < N;
+            E[j] = real ? E[j] : 0.0; CS[j] = real ? CS[j] : 0.0; d1[j] = real ? d1[j] : 0.0; d2[j] = real ? d2[j] : 0.0;
+            SRR()[i] = real ? rr[j] : 0.0;
+            const int ls = real ? lsw[j] : 0; SLS()[i] = ls;
+            if constexpr (HEAVY) SRCV()[i] = real ? rcw[j] : -1;
+            am |= (unsigned)(ls & 1) << j;
         }
+        uint64_t* la = (uint64_t*)SAG(); uint64_t* lt = (uint64_t*)STH();
+#pragma unroll
+        for (int k = 0; k < kAgT; ++k) { const int w = lane + 64 * k; if (w < nag) la[w] = va[k]; }
+#pragma unroll
+        for (int k = 0; k < kThT; ++k) { const int w = lane + 64 * k; if (w < nth) lt[w] = vt[k]; }
+#pragma unroll
+        for (int k = 0; k < kCnT; ++k) { const int w = lane + 64 * k; if (w < ncn) { SCONN()[w] = vc[k]; SCONNXY()[2 * w] = vx[k]; SCONNXY()[2 * w + 1] = vy[k]; } }
         for (int w = lane; w <= M; w += 64) { SCTR()[w] = 0; SCP()[w] = 0; SCA()[w] = 0; SCT()[w] = 0; SCS()[w] = 0; }
-        if (lane == 0) { SREQ()[0] = 0; SREQ()[1] = 0; SREQ()[2] = dy->n_connected; SS()->n_events = dy->n_events; SURN()[0] = 0; }
+        if (lane == 0) { SREQ()[0] = 0; SREQ()[1] = 0; SREQ()[2] = n_conn0; SS()->n_events = n_ev0; SURN()[0] = 0; }
         __syncthreads();
         WRSN_PROF_ADD(10)
     }
 
     WDEV void store(const WrsnNodeArrays& a, int terminal_pending, int64_t n_steps_add, int susp = 0) { WRSN_PROF_T0
         __syncthreads();
-        size_t nb = (size_t)env * NP;
+        const size_t nb = (size_t)env * NP;
+        const auto gE = wrsn_global(a.E + nb), gCS = wrsn_global(a.CS + nb), gd1 = wrsn_global(a.d1 + nb), gd2 = wrsn_global(a.d2 + nb), gRR = wrsn_global(a.RR + nb);
+        const auto gls = wrsn_global(a.ls + nb), grcv = wrsn_global(a.rcv + nb);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             if (i < N) {                                   // arrays nothing touched since load() are not written back
-                a.E[nb + i] = E[j]; a.RR[nb + i] = SRR()[i];
-                if (dirty & 4) a.CS[nb + i] = CS[j];
+                gE[i] = E[j]; gRR[i] = SRR()[i];
+                if (dirty & 4) gCS[i] = CS[j];
                 if (dirty & 1) {
-                    a.d1[nb + i] = d1[j]; a.d2[nb + i] = d2[j];
+                    gd1[i] = d1[j]; gd2[i] = d2[j];
                     // (the lean variant never changes the routing cache; it writes it only when an auto-reset restores the snapshot, and
                     //  then the receivers, which it does not stage, go from the snapshot to the live array directly)
-                    if constexpr (HEAVY) a.rcv[nb + i] = SRCV()[i]; else a.rcv[nb + i] = dp->snap.rcv[nb + i];
+                    if constexpr (HEAVY) grcv[i] = SRCV()[i]; else grcv[i] = wrsn_global(dp->snap.rcv + nb)[i];
                 }
-                if (dirty & 2) a.ls[nb + i] = SLS()[i];
+                if (dirty & 2) gls[i] = SLS()[i];
             }
         }
-        WrsnEnvDyn* dy = a.dyn + env;
+        WrsnEnvDyn WRSN_GLOBAL_AS* dy = wrsn_global(a.dyn + env);
         if (lane == 0) {
             dy->now = now; dy->seq = seq; dy->net_time = net_time; dy->net_seq = net_seq; dy->ur_time = ur_time; dy->ur_seq = ur_seq;
             dy->node_time = node_time; dy->node_seq = node_seq; dy->last_minfit = last_minfit; dy->opmax = opmax;
@@ -473,12 +538,12 @@ struct Sim {
             dy->ring_head = ring_head; dy->safe_ticks = safe_ticks; dy->frozen = frozen; dy->n_connected = SREQ()[2];
             dy->terminal_pending = terminal_pending; dy->error = err; dy->log_pending = log_pending; dy->susp = susp; dy->fit_dirty = fit_dirty; dy->map1_valid = map1_valid;
         }
-        uint64_t* ga = (uint64_t*)dy->ag; const uint64_t* la = (const uint64_t*)SAG();
+        const auto ga = wrsn_global((uint64_t*)(a.dyn + env)->ag); const uint64_t* la = (const uint64_t*)SAG();
         for (int w = lane; w < M * (int)(sizeof(WrsnAgent) / 8); w += 64) ga[w] = la[w];
-        uint64_t* gt = (uint64_t*)dy->th; const uint64_t* lt = (const uint64_t*)STH();
+        const auto gt = wrsn_global((uint64_t*)(a.dyn + env)->th); const uint64_t* lt = (const uint64_t*)STH();
         for (int w = lane; w < 2 * M * (int)(sizeof(WrsnThread) / 8); w += 64) gt[w] = lt[w];
-        int16_t* gc = a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP;
-        double* gr = a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2;
+        const auto gc = wrsn_global(a.conn + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP);
+        const auto gr = wrsn_global(a.conn_xy + (size_t)env * WRSN_MAX_MC * WRSN_CONN_CAP * 2);
         for (int w = lane; w < M * CC; w += 64) {
             const int g = (w / CC) * WRSN_CONN_CAP + (w % CC);
             gc[g] = SCONN()[w]; gr[2 * g] = SCONNXY()[2 * w]; gr[2 * g + 1] = SCONNXY()[2 * w + 1];
@@ -506,7 +571,7 @@ struct Sim {
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const int i = j * 64 + lane;
-                const U4 lo = ADJM()[(size_t)i * 2], hi = ADJM()[(size_t)i * 2 + 1];
+                const U4 lo = wrsn_ld_u4(ADJM() + (size_t)i * 2), hi = wrsn_ld_u4(ADJM() + (size_t)i * 2 + 1);
                 const unsigned long long m[4] = {((unsigned long long)lo.y << 32) | lo.x, ((unsigned long long)lo.w << 32) | lo.z,
                                                  ((unsigned long long)hi.y << 32) | hi.x, ((unsigned long long)hi.w << 32) | hi.z};
 #pragma unroll
@@ -538,7 +603,7 @@ struct Sim {
         // level then reads them from LDS instead of from the table in global memory
         U4* snb = (U4*)SU();
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) snb[j * 64 + lane] = NBP()[j * 64 + lane];
+        for (int j = 0; j < NPL; ++j) snb[j * 64 + lane] = wrsn_ld_u4(NBP() + (j * 64 + lane));
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
@@ -963,6 +1028,9 @@ struct Sim {
         else {
             fast = second_is_safe(rrh);
             if (!HEAVY && !fast) { need_heavy = 1; return; }  // nothing was touched: the full variant takes this item again
+            // time-sliced launch about to end: a packet-exact second is not begun (unless nothing else was done in this visit); the
+            // environment stops in front of the item and the next launch, in which it is among the first, takes it again
+            if (!fast && t_exact != 0 && n_items > 0 && (long long)wall_clock64() > t_exact) { need_heavy = 1; return; }
         }
         if (fast) {
             if (any_rr) {
@@ -1384,7 +1452,7 @@ struct Sim {
                 if ((irr || guarded) && j > 1) j = 1;
                 if (t_deadline != 0 && j > 8 && (any_rr || ur_flag)) {
                     // what is left of the launch, in seconds of the time-parallel steady path (about 0.35 us each, 35 ticks of the 100 MHz clock)
-                    const long long left = (t_deadline - (long long)wall_clock64()) / 35;
+                    const long long left = (t_deadline - (long long)wall_clock64()) / WRSN_TICKS_PER_FUSED_SECOND;
                     if ((long long)j > left) j = left > 8 ? (int)left : 8;
                 }
                 if (j >= 1) {
@@ -1399,7 +1467,7 @@ struct Sim {
                     ur_time = ke + 1.0; node_time = ke + 1.0 * 0.5;
                     if (net_active) { net_time = ke + 1.0 / 10.0; seq += 5 * (int64_t)j; ur_seq = seq - 3; net_seq = seq - 2; node_seq = seq - 1; }
                     else { seq += 3 * (int64_t)j; ur_seq = seq - 2; node_seq = seq - 1; }
-                    now = ke; n_ticks += j; if (!guarded) safe_ticks -= j;
+                    now = ke; n_ticks += j; n_items += j; if (!guarded) safe_ticks -= j;
                     if (!fused) continue;
                 }
             }
@@ -1426,11 +1494,12 @@ struct Sim {
                 } else {
                     if (node_phase == 0) {
                         node_half(rrh, any_rr);
-                        if (!HEAVY && need_heavy) { now = now_before; break; }
+                        if (need_heavy) { now = now_before; break; }
                         node_phase = 1;
                     } else { node_full(rrh, any_rr); node_phase = 0; }
                     node_time = now + 1.0 * 0.5; node_seq = seq++;
                 }
+                n_items++;
                 WRSN_PROF_MARK(gi1_) WRSN_PROF_SPAN(8, gi0_, gi1_)
             }
             // ---- the steady loop: k+0.5 drain and half-charge (Node.py:60), reward instant, k+1.0 half-charge (Node.py:68),
@@ -1937,7 +2006,7 @@ struct Sim {
     // not idempotent).  Deterministic: the launch a request appears in does not depend on timing.
     WDEV bool run(bool use_limit, double limit, int budget_ = 0) {
         double svc = 0.0;
-        work = 0; budget = budget_;
+        work = 0; budget = budget_; n_items = 0;
         bool suspended = false, stopped = false;
         for (long guard = 0; guard < 8000000L; ++guard) {
             WRSN_P4_MARK(r0_)
@@ -1967,7 +2036,7 @@ struct Sim {
             }
             __syncthreads();
             WRSN_P4_MARK(r4_) if (req == REQ_GRID) { WRSN_P4_SPAN(14, r3_, r4_) } else if (req == REQ_PRECHECK) { WRSN_P4_SPAN(12, r3_, r4_) } else { WRSN_P4_SPAN(13, r3_, r4_) }
-            if (!HEAVY && need_heavy) { suspended = true; break; }   // the full variant goes on in front of this grid item
+            if (need_heavy) { suspended = true; break; }     // lean: the full variant goes on in front of this grid item; full: put off to the next launch
         }
         if (!stopped && !suspended) err = -10;               // the service loop ran out: the environment is stuck, report it (status < 0)
         __syncthreads();
@@ -2064,7 +2133,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
 template <int NPL, bool HEAVY>
 __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
                                               const double* __restrict__ action, int auto_reset, int budget, long long epoch,
-                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem);
+                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem, long long t_end);
 
 template <int NPL, bool HEAVY>
 __global__ void __launch_bounds__(64, HEAVY ? WRSN_WAVES_PER_SIMD(NPL) : WRSN_WAVES_PER_SIMD_LEAN(NPL))
@@ -2077,8 +2146,27 @@ wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* 
     // in the order, so a launch owns an environment through one block only.
     // The heavy launch has one block per environment of the batch too; block b takes entry b of the list and the blocks behind the end of the
     // list leave at once (the host does not know its length).
-    int env = blockIdx.x;
-    if (handoff == 2) {
+    int env = blockIdx.x; long long t_slice_end = 0;
+    if (handoff == 3) {
+        // Time-sliced launch (wrsn_set_step_deadline): the blocks of the launch share ONE deadline (`deadline` ticks after the first of them
+        // started).  Block b takes environment (start + b) mod B of this launch's cyclic order; the hardware hands the blocks to the wave slots
+        // in index order as slots become free, so every slot is busy from the first microsecond on.  A wave runs its WRSN.step until it
+        // returns or the deadline passes (then it stops at the next item boundary, like a wave out of budget).  A block that only starts
+        // when the launch is about to end leaves at once and does NOT touch its environment: the action waits in the latch
+        // (wrsn_latch_kernel), the row says "in flight", and the next launch starts its cyclic order there.
+        const int B = dp->B;
+        if ((int)blockIdx.x >= B) return;
+        // (the launch's start was stamped by wrsn_latch_kernel, a few microseconds ago: thousands of blocks racing for one stamp with an
+        //  atomic -- and for one "last block taken" word -- took 70 us to get going; the word is spread over 64 addresses)
+        const long long tn = (long long)wall_clock64();       // wave-uniform (s_memrealtime)
+        const long long t_end = wu((int64_t)*dp->launch_t0) + deadline;
+        // too late to do anything for this environment in this launch?  (margin: at most a quarter of the time slice)
+        if (tn > t_end - (deadline / 4 < WRSN_PULL_MARGIN ? deadline / 4 : WRSN_PULL_MARGIN) && blockIdx.x != 0) return;
+        if (threadIdx.x == 0) atomicMax(&dp->queue[8 + (blockIdx.x & 63)], (int)blockIdx.x + 1);    // the next launch starts behind the last environment taken
+        env = dp->queue[1] + (int)blockIdx.x; env = env >= B ? env - B : env;
+        if (dp->qskip[env]) return;
+        t_slice_end = t_end;
+    } else if (handoff == 2) {
         if ((int)blockIdx.x >= dp->heavy_n[(int)(epoch & 1)]) return;
         env = dp->heavy_list[(size_t)(epoch & 1) * dp->B + blockIdx.x];
         // (a reset between the two calls takes the stamp away; a row the caller marks -2 is left alone -- the lean launch of the next call
@@ -2102,29 +2190,36 @@ wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* 
         }
     }
     if (env < 0 || env >= dp->B) return;
-    wrsn_step_env<NPL, HEAVY>(dp, env, reset_call, agent_id, action, auto_reset, budget, epoch, env_mask, out, handoff, deadline, smem);
+    wrsn_step_env<NPL, HEAVY>(dp, env, reset_call, agent_id, action, auto_reset, budget, epoch, env_mask, out, handoff, deadline, smem, t_slice_end);   // the one call site
 }
 
 template <int NPL, bool HEAVY>
 __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
                                               const double* __restrict__ action, int auto_reset, int budget, long long epoch,
-                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem) {
+                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem, long long t_end) {
     const int lane = threadIdx.x;
     bool do_reset = reset_call != 0;
     // a row nobody handles in this launch is not rendered and none of its outputs is touched
     if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
     int aid = -1, resume = 0;
+    const double* act_src = action + (size_t)env * 3;
     if (handoff == 2) resume = 1;                          // handed over by the previous call's lean launch: the step is in flight
-    else if (!reset_call) {
+    else if (handoff == 3) {                               // work-queue launch: the action waits in the latch, the caller's row is not looked at
+        const WrsnEnvDyn* dy = dp->live.dyn + env;
+        resume = dy->susp;
+        if (!resume) { if (!dy->lat_valid) return; aid = dy->lat_agent; act_src = dy->lat_action; }
+        if (auto_reset && dy->terminal_pending) do_reset = true;
+    } else if (!reset_call) {
         aid = agent_id[env];
         if (aid == -2) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
         resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
-    if (reset_call && lane == 0) dp->heavy_epoch[env] = 0; // a reset environment is nobody's hand-off any more
+    if (reset_call && lane == 0) { dp->heavy_epoch[env] = 0; dp->live.dyn[env].lat_valid = 0; }   // a reset environment is nobody's hand-off any more, and holds no action
     Sim<NPL, HEAVY> s;
     s.bind(dp, env, lane, smem);
-    if (deadline > 0 && budget > 0 && !reset_call) {         // common deadline of the launch: `deadline` ticks after its first wave started
+    if (handoff == 3) { s.t_deadline = t_end; s.t_exact = t_end - (deadline / 2 < WRSN_EXACT_MARGIN ? deadline / 2 : WRSN_EXACT_MARGIN); }   // the time-sliced launch stamped its start itself
+    else if (deadline > 0 && budget > 0 && !reset_call) {    // common deadline of the launch: `deadline` ticks after its first wave started
         long long t0 = 0;
         const long long tn = (long long)wall_clock64();      // wave-uniform (s_memrealtime)
         if (lane == 0) {
@@ -2177,7 +2272,7 @@ __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, in
             dp->live.dyn[env].step_t0 = s.now;
             if (aid >= 0 && aid < s.M) {
                 double act[3];
-                for (int k = 0; k < 3; ++k) { double v = action[(size_t)env * 3 + k]; act[k] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }   // np.clip (WRSN.py:299)
+                for (int k = 0; k < 3; ++k) { double v = act_src[k]; act[k] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); }   // np.clip (WRSN.py:299)
                 s.SAG()[aid].action[0] = act[0]; s.SAG()[aid].action[1] = act[1]; s.SAG()[aid].action[2] = act[2];
                 double p0 = act[0] * (ec->frame[1] - ec->frame[0]) + ec->frame[0];  // translate (WRSN.py:95-98)
                 double p1 = act[1] * (ec->frame[3] - ec->frame[2]) + ec->frame[2];
@@ -2263,12 +2358,47 @@ __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, in
 #endif
     }
     if (lane == 0 && !do_reset) dp->live.dyn[env].tot_ticks += s.n_ticks - ticks0;
+    if (handoff == 3 && lane == 0 && (!resume || do_reset)) dp->live.dyn[env].lat_valid = 0;   // the latched action has been taken up
 #ifdef WRSN_PROFILE
     if (lane == 0) { for (int q_ = 0; q_ < 24; ++q_) dp->counters[(size_t)env * 24 + q_] += s.prof_[q_]; dp->counters[(size_t)dp->B * 24 + env] += clock64() - kt0_; }
 #if WRSN_PROFILE >= 3
     if (lane == 0) { dp->counters[(size_t)env * 24 + 22] = wt0_; dp->counters[(size_t)env * 24 + 23] = wall_clock64(); }
 #endif
 #endif
+}
+
+// ------------------------------------------------------------------ work-queue launches: latch the actions, preset the rows
+// wrsn_latch_kernel runs in front of a work-queue step launch (wrsn_set_step_deadline), one thread per environment:
+//   * a row the caller marks -2 is nobody's in this call (qskip);
+//   * a fresh action (the environment has no step in flight and nothing latched) goes into the environment's latch: the wave that takes
+//     the environment up -- in this launch or a later one -- starts the WRSN.step from there;
+//   * every row is preset to "in flight" (agent -1, status 4, not rendered); the waves overwrite the rows of the environments they finish;
+//   * thread 0 moves the start of the cyclic order behind the environments the previous launch handed out and rewinds the queue.
+__global__ void __launch_bounds__(256) wrsn_latch_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ action, WrsnStepOutDev out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const long long tn = (long long)wall_clock64();
+    if (e == 0) {
+        int handed = 0;
+        for (int k = 0; k < 64; ++k) { handed = d.queue[8 + k] > handed ? d.queue[8 + k] : handed; d.queue[8 + k] = 0; }
+        handed = handed < d.B ? handed : d.B;
+        int st = d.queue[1] + handed; st = st >= d.B ? st - d.B : st;
+        d.queue[1] = st; *d.launch_t0 = tn;                   // the time slice of the step launch behind this kernel starts now
+    }
+    if (e >= d.B) return;
+    const int aid = agent_id[e];
+    if (aid == -2) { d.qskip[e] = 1; d.render_agent[e] = -1; d.row_state[e] = 0; return; }
+    d.qskip[e] = 0;
+    WrsnEnvDyn* dy = d.live.dyn + e;
+    if (!dy->susp && !dy->lat_valid) {
+        dy->lat_agent = aid; dy->lat_action[0] = action[(size_t)e * 3]; dy->lat_action[1] = action[(size_t)e * 3 + 1]; dy->lat_action[2] = action[(size_t)e * 3 + 2];
+        dy->lat_valid = 1;
+    }
+    if (out.agent_id) out.agent_id[e] = -1;
+    if (out.reward) out.reward[e] = 0.0;
+    if (out.terminal) out.terminal[e] = 0;
+    if (out.now) out.now[e] = dy->now;
+    if (out.status) out.status[e] = 4;
+    d.render_agent[e] = -1; d.row_state[e] = 3;
 }
 
 // ------------------------------------------------------------------ launch order of a step call: longest job first

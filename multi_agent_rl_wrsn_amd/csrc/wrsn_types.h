@@ -66,6 +66,9 @@ struct WrsnEnvDyn {
     int32_t fit_dirty, map1_valid;           // node state changed (a grid service ran) since last_minfit was evaluated / since map 1 of the
     uint64_t map1_ptr;                       // observation was rendered into the row at this address (wrsn_set_obs_reuse; written by the observation kernel)
     int32_t n_connected, error, log_pending, susp;   // susp: WRSN.step in flight (work budget of a launch used up)
+    // work-queue launches (wrsn_set_step_deadline): the action of a WRSN.step call that no wave has taken up yet (wrsn_latch_kernel); the
+    // environment may wait for its turn over several launches, during which the caller's row says "in flight" and is ignored
+    int32_t lat_valid, lat_agent; double lat_action[3];
     // the `|` conditions of the step in flight (WRSN.py:307-311); only meaningful while susp != 0
     double cond_time[WRSN_MAX_MC + 1]; int64_t cond_seq[WRSN_MAX_MC + 1];
     int32_t cond_agent[WRSN_MAX_MC + 1], cond_trig[WRSN_MAX_MC + 1], cond_pend[WRSN_MAX_MC + 1], cond_L;
@@ -120,6 +123,10 @@ struct WrsnDev {
                                       //        (fresh request), 2 reset / auto-reset request, 3 step still in flight, 4 terminal return
     long long *launch_t0;             // [1]    wall clock (100 MHz) at which the first wave of the current step launch started; zeroed by the
                                       //        sort kernel in front of it (wrsn_set_step_deadline)
+    // time-sliced launches: queue[1] = environment the cyclic order of this launch starts at, queue[8 + (b & 63)] = 1 + the last block b that
+    // took its environment (spread over 64 words: one word is a serial point for thousands of starting blocks)
+    int32_t *queue;                   // [8 + 64]
+    uint8_t *qskip;                   // [B]    the caller marked the row -2 in this call: nobody takes the environment
     int32_t *render_agent;            // [B]    charger whose observation the launch's render pass draws (-1: none); written by the
                                       //        environment kernel for every row, including the rows it leaves untouched
 };

@@ -37,9 +37,10 @@ class VecWRSN:
                 environment whose step is still in flight reports status 4 / agent_id -1 and simply goes on in the
                 next `step` (its agent_id / action row is ignored).  Requests are identical either way; only the
                 launch they appear in differs, so a batch no longer waits for its slowest environment.
-    step_deadline_us: with a step budget, a common deadline of a launch (microseconds after its first wave started): waves still
-                running then stop at the next item boundary like waves out of budget, late waves get what is left of the launch
-                (`wrsn_set_step_deadline`).  Same requests; which launch reports one then depends on timing.
+    step_deadline_us: > 0 = time-sliced launches (`wrsn_set_step_deadline`): every launch lasts about that long; the waves walk the
+                environments in a cyclic order, an environment whose step is not finished (or not even begun: its action then waits in a
+                latch inside the library) reports status 4 / agent_id -1 and goes on in the following launches.  Same requests; which
+                launch reports one depends on timing.  May be combined with a step budget (a cap per visit).
     """
 
     def __init__(self, scenarios, agent_type=None, num_agent=3, map_size=100, warm_up_time=100, device="cuda:0",

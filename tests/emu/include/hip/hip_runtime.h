@@ -23,6 +23,9 @@
 #define __shared__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define WRSN_GLOBAL_AS                       /* one address space here */
+#define WRSN_LD_U4_DEFINED
+template <typename T> inline T wrsn_ld_u4(const T* p) { return *p; }
 
 struct alignas(16) float4 { float x, y, z, w; };
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
@@ -169,6 +172,7 @@ inline wrsn_v16f emu_mfma_32x32x2(float a, float b, wrsn_v16f c, int, int, int) 
 
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 inline float __expf(float x) { return expf(x); }
 
 extern int emu_block_order;                  // 0: blocks run in index order, 1: in reverse order (HIP promises no order)

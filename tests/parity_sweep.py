@@ -15,7 +15,7 @@ def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
     """returns (requests compared, finished episodes, noise-dependent requests); raises AssertionError on a mismatch"""
     M = int(os.environ.get("WRSN_M", "3"))
     scs = [synth_scenario(seed0 + e, N, N) for e in range(B)]
-    env = VecWRSN(scs, None, M, step_budget=budget, step_deadline_us=(int(os.environ.get("WRSN_DEADLINE_US", "0")) if budget > 0 else 0))
+    env = VecWRSN(scs, None, M, step_budget=budget, step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")))
     ors = [OracleWRSN(s.node_xy, s.target_xy, s.bs_xy, s.node_spec, DEFAULT_MC_SPEC, s.max_time, M) for s in scs]
     r = env.reset(); env.synchronize()
     last = [o.reset() for o in ors]

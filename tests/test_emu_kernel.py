@@ -570,3 +570,73 @@ def test_emulated_split_launches_return_the_same_requests(monkeypatch):
             assert n >= 20 and sum(q[4] for q in split[e][:n]) >= 1          # whole episodes, terminal returns included
             for a, b in zip(full[e][:n], split[e][:n]):
                 assert a[:3] == b[:3] and a[4] == b[4] and abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(a[3])), (e, a, b)
+
+
+def test_emulated_work_queue_launches_return_the_same_requests():
+    """wrsn_set_step_deadline = work-queue launches: persistent waves hand the environments out among themselves in a cyclic order until
+    the common deadline of the launch; an environment nobody reaches is not touched -- its action waits in the latch over as many launches
+    as it takes, its row says "in flight".  With auto-reset, rows marked -2 and a masked reset of an environment whose action is still
+    latched: per environment the sequence of requests is the blocking run's (only the call that reports a request differs)."""
+    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
+    B, M, G = 5, 2, 12
+    scs = [synth_scenario(300 + e, 70, 60) for e in range(B)]
+
+    def act_of(e, n):
+        return np.random.RandomState(1000 * e + n).rand(3)
+
+    def run(deadline_us, calls, pause):
+        ev = _emu(scs, DEFAULT_MC_SPEC, M, map_size=G)
+        if deadline_us:
+            ev.h.set_step_deadline(deadline_us)
+        ev.reset()
+        hist = [[] for _ in range(B)]; n_flight = 0; n_given = np.zeros(B, dtype=int)
+        for it in range(calls):
+            ids = ev.agent_id.copy()
+            act = np.stack([act_of(e, n_given[e]) for e in range(B)])
+            fresh = (ev.status != 4)                          # rows that carry a request: the action passed now starts their next WRSN.step
+            if pause and it % 7 == 3:
+                ids[1] = -2
+            keep = (ev.agent_id[1], ev.now[1], ev.reward[1], ev.status[1])
+            ev.step(ids, act, auto_reset=True)
+            if ids[1] == -2:
+                assert (ev.agent_id[1], ev.now[1], ev.reward[1], ev.status[1]) == keep
+            for e in range(B):
+                if ids[e] == -2:
+                    continue
+                if fresh[e]:
+                    n_given[e] += 1                            # (also counts the ignored row of an auto-reset call: both runs do the same)
+                if ev.status[e] == 4:
+                    n_flight += 1
+                else:
+                    hist[e].append((int(ev.status[e]), int(ev.agent_id[e]), float(ev.now[e]), float(ev.reward[e]), int(ev.terminal[e])))
+        return hist, n_flight
+    full, nf0 = run(0, 120, False)
+    assert nf0 == 0
+    for pause in (False, True):
+        q, n_flight = run(20, 700, pause)                      # 40 readings of the stand-in clock (50 ticks each) per launch: a fraction of one WRSN.step
+        assert n_flight > 200
+        for e in range(B):
+            n = min(len(full[e]), len(q[e]))
+            assert n >= 15 and sum(x[4] for x in q[e][:n]) >= 1, (e, n)
+            for a, b in zip(full[e][:n], q[e][:n]):
+                assert a[:3] == b[:3] and a[4] == b[4] and abs(a[3] - b[3]) <= 1e-7 * max(1.0, abs(a[3])), (e, a, b)   # a suspension splits a closed form / re-bases the float32 priorities: ~1e-9
+    # a masked reset drops a latched action: the environment answers the reset, then takes the NEXT action it is given
+    ev = _emu(scs, DEFAULT_MC_SPEC, M, map_size=G)
+    ev.h.set_step_deadline(1)
+    ev.reset()
+    ev.step(ev.agent_id.copy(), np.full((B, 3), 0.9), auto_reset=True)
+    untouched = [e for e in range(B) if ev.status[e] == 4 and ev.now[e] == 100.0 and ev.env_info()["n_events"][e] == ev.env_info()["n_events"].min()]
+    assert len(untouched) >= 1
+    e = untouched[-1]
+    mask = np.zeros(B, dtype=np.uint8); mask[e] = 1
+    ev.h.reset(mask.ctypes.data, **ev._ptrs(True))
+    assert ev.agent_id[e] == 0 and ev.now[e] == 100.0
+    ref = _emu([scs[e]], DEFAULT_MC_SPEC, M, map_size=G); ref.reset(); ref.step([0], np.array([[0.2, 0.3, 0.1]]))
+    ids = np.full(B, -2, dtype=np.int32); ids[e] = 0
+    act = np.zeros((B, 3)); act[e] = [0.2, 0.3, 0.1]
+    for it in range(3000):
+        ev.step(ids, act, auto_reset=False)
+        if ev.status[e] != 4:
+            break
+        ids[e] = -1
+    assert ev.status[e] == 0 and ev.agent_id[e] == ref.agent_id[0] and ev.now[e] == ref.now[0] and abs(ev.reward[e] - ref.reward[0]) < 1e-12

@@ -31,3 +31,11 @@ for rep in range(3):
     print("  end-time percentiles (us): p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f" % tuple(np.percentile(t1, [50, 90, 99, 99.9, 100])))
     long_ = (t1 - t0) > 0.6 * (t1 - t0).max()
     print("  long waves: %d, their start p50 %.0f p90 %.0f max %.0f" % (long_.sum(), *np.percentile(t0[long_], [50, 90, 100])))
+    dur = t1 - t0
+    slots = 2048
+    print("  slot utilisation: %.1f %% of %d slots x span; wave durations us: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f; sum %.0f slot-us" % (100.0 * dur.sum() / (slots * t1.max()), slots, *np.percentile(dur, [10, 50, 90, 99, 100]), dur.sum()))
+    order = np.argsort(t0)
+    late = order[slots:]                                   # waves that had to wait for a slot
+    print("  second-round waves: %d, start p10 %.0f p50 %.0f p90 %.0f; their durations p50 %.0f p90 %.0f max %.0f; in flight after the launch %d" % (len(late), *np.percentile(t0[late], [10, 50, 90]), *np.percentile(dur[late], [50, 90, 100]), int((st[late] == 4).sum())))
+    first = order[:slots]
+    print("  first-round waves: durations p10 %.0f p50 %.0f p90 %.0f max %.0f; in flight after the launch %d" % (*np.percentile(dur[first], [10, 50, 90, 100]), int((st[first] == 4).sum())))
