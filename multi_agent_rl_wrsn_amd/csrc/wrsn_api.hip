@@ -75,6 +75,9 @@ struct wrsn_handle {
     long long epoch;           // counter of wrsn_step calls (its parity selects the hand-off list a budgeted call reads / writes)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     int deadline_ticks;        // wrsn_set_step_deadline in 100 MHz wall-clock ticks, 0 = none
+    int pipe_swap;             // 1: the short stage runs on the caller's stream (it is launched first), the long stage on the second one
+    int pipe_short_pct;        // work cap of the short stage in per cent of the step budget (its stragglers go on in the next call)
+    int pipe, pipe_long_pct;   // step calls that render as a two-stage pipeline over the launch order (WRSN_PIPE=0 disables); share of the long stage
     int split;                 // budgeted steps as lean launch + concurrent heavy launch over the hand-off list (WRSN_SPLIT=1; diagnostic)
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
@@ -142,8 +145,11 @@ int configure_launch(wrsn_handle* h) {
     return 0;
 }
 
+int launch_obs(wrsn_handle* h, const int32_t* agent_id, float* obs);
+
+// `obs_pipe` (step calls that render): the observations of this call are launched from here, interleaved with the step launches (below)
 int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agent_id, const double* action,
-               int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out) {
+               int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out, float* obs_pipe = nullptr) {
     const int lds = h->lds_env + h->lds_pad, lds_lean = h->lds_lean + h->lds_pad;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
@@ -161,7 +167,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     // stream: the lean variant (no code for those services, three waves per SIMD) over everybody else.  The heavy launch needs nothing of this
     // call but the list, so it starts at once and the two overlap; the observation kernel waits for both.
 #define WRSN_HEAVY(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream2, (const WrsnDev*)h->d_dev, \
-                                           0, agent_id, action, 0, budget, epoch, 0, mask, out, 2, 0)
+                                           0, agent_id, action, 0, budget, epoch, 0, mask, out, 2, 0, 0)
     if (split) {
         (void)hipEventRecord(h->ev_fork, h->stream);
         (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
@@ -177,13 +183,24 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
         if (timed) (void)hipEventRecord(h->ev[1], h->stream);
         const int qbudget = budget > 0 ? budget : (1 << 28);   // the deadline is looked at wherever a work budget is
 #define WRSN_QUEUE(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, 0, agent_id, action, \
-                                           auto_reset, qbudget, epoch, 0, mask, out, 3, h->deadline_ticks)
+                                           auto_reset, qbudget, epoch, 0, mask, out, 3, h->deadline_ticks, 0)
         WRSN_NPL_SWITCH(h->npl, WRSN_QUEUE, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
 #undef WRSN_QUEUE
         if (timed) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; h->ev_rec = 1; }
         HIPCHK(hipGetLastError());
+        if (obs_pipe) {
+            int rc = launch_obs(h, h->dev.render_agent, obs_pipe);
+            if (timed) { (void)hipEventRecord(h->ev[4], h->stream); h->ev_obs = 1; }
+            return rc;
+        }
         return 0;
     }
+    // A step call that renders, as a PIPELINE over the two halves of the launch order (longest job first): the short half is stepped on the
+    // second stream and rendered there as soon as it is done -- nearly all of its steps complete, it carries ~60 % of the observations of
+    // the call -- while the long half (work-capped or slow steps, the tail of the launch) is still being stepped on the caller's stream;
+    // only the observations of the long half are left for afterwards.  The step kernel is bound by instruction issue and latency and leaves
+    // the HBM idle, the observation kernel is a 160 KB store stream per row: they overlap well.  Same blocks, same budgets, same results.
+    const bool pipe = obs_pipe && mode == WRSN_MODE_STEP && !split && h->pipe && h->ev2_ok && h->bp2 > 0 && nenv >= 512 && nenv == h->dev.B;
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
         hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2,
@@ -207,20 +224,46 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else if (split) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds_lean, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 1, dl);                                         \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 1, dl, 0);                                      \
+    else if (pipe) {                                                                                                    \
+        const int n_long = (nenv * h->pipe_long_pct / 100 + 63) & ~63;                                                 \
+        const int b_short = budget > 0 ? (budget * h->pipe_short_pct / 100 > 64 ? budget * h->pipe_short_pct / 100 : 64) : 0; \
+        hipStream_t s_short = h->pipe_swap ? h->stream : h->stream2, s_long = h->pipe_swap ? h->stream2 : h->stream;   \
+        (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);              \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv - n_long), block, lds, s_short, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                           auto_reset, b_short, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, n_long);                                 \
+        hipLaunchKernelGGL(wrsn_obs_kernel, dim3(nenv - n_long), dim3(256), h->lds_obs, s_short, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, n_long); \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(n_long), block, lds, s_long, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0);                                       \
+        if (timed && !h->pipe_swap) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); } \
+        hipLaunchKernelGGL(wrsn_obs_kernel, dim3(n_long), dim3(256), h->lds_obs, s_long, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, 0); \
+        (void)hipEventRecord(h->ev_join, h->stream2);                                                                 \
+        (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);                                                            \
+        if (timed && h->pipe_swap) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); } \
+    }                                                                                                                  \
     else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl)
+                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0)
     WRSN_NPL_SWITCH(h->npl, WRSN_LAUNCH, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
 #undef WRSN_LAUNCH
+    if (pipe) {
+        if (timed) { (void)hipEventRecord(h->ev[4], h->stream); h->ev_obs = 1; h->ev_rec = 1; }
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if (timed) (void)hipEventRecord(h->ev[2], h->stream);
     if (split) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);   // whatever follows on the caller's stream sees both launches
     if (timed) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; h->ev_rec = 1; }
     HIPCHK(hipGetLastError());
+    if (obs_pipe) {
+        int rc = launch_obs(h, h->dev.render_agent, obs_pipe);
+        if (timed) { (void)hipEventRecord(h->ev[4], h->stream); h->ev_obs = 1; }
+        return rc;
+    }
     return 0;
 }
 
 int launch_obs(wrsn_handle* h, const int32_t* agent_id, float* obs) {
-    hipLaunchKernelGGL(wrsn_obs_kernel, dim3(h->dev.B), dim3(256), h->lds_obs, h->stream, h->dev, agent_id, obs, h->obs_reuse);
+    hipLaunchKernelGGL(wrsn_obs_kernel, dim3(h->dev.B), dim3(256), h->lds_obs, h->stream, h->dev, agent_id, obs, h->obs_reuse, (const int32_t*)nullptr, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -274,8 +317,19 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     // WRSN_SPLIT=1: budgeted calls as lean launch + concurrent heavy launch (measured in r03, profiles/r03_split_experiment.log: slower than the
     // one full launch at every budget -- the hand-off costs an environment the rest of its launch; kept as a diagnostic, parity-tested)
     { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
+    { const char* e = std::getenv("WRSN_PIPE"); h->pipe = (e && *e == '0') ? 0 : 1; }
+    { const char* e = std::getenv("WRSN_PIPE_SWAP"); h->pipe_swap = (e && *e == '1') ? 1 : 0; }
+    { const char* e = std::getenv("WRSN_PIPE_SHORT_PCT"); h->pipe_short_pct = e ? std::atoi(e) : 40; if (h->pipe_short_pct < 5 || h->pipe_short_pct > 100) h->pipe_short_pct = 40; }
+    { const char* e = std::getenv("WRSN_PIPE_LONG_PCT"); h->pipe_long_pct = e ? std::atoi(e) : 50; if (h->pipe_long_pct < 10 || h->pipe_long_pct > 90) h->pipe_long_pct = 50; }
     h->stream2 = nullptr; h->ev2_ok = 0; h->cc_bound = 0; h->cus = 256;
-    if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess) {
+    // the second stream: high priority by default (WRSN_STREAM2_PRIO=0: normal) -- its launch is the SHORT half of a pipelined step call, whose
+    // blocks should get wave slots first so that its observations can be rendered while the long half is still being stepped
+    hipError_t se = hipErrorUnknown;
+    { const char* e = std::getenv("WRSN_STREAM2_PRIO"); const bool hi = !(e && *e == '0');
+      int lo_p = 0, hi_p = 0;
+      if (hi && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hi_p != lo_p) se = hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi_p);
+      if (se != hipSuccess) se = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking); }
+    if (se == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess) {
         if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess) h->ev2_ok = 1; else (void)hipEventDestroy(h->ev_fork);
     }
     {   // budget taper over the launch order (units of slots / 8 blocks): start 8 = after the first `slots` blocks, length 16 = down to
@@ -441,14 +495,7 @@ int wrsn_step(wrsn_t* h, const int32_t* agent_id, const double* action, int32_t 
     // rows with agent_id -2 keep every output (their pending request included)
     WrsnStepOutDev o; o.agent_id = out->agent_id; o.reward = out->reward; o.terminal = out->terminal;
     o.now = out->now; o.obs = out->obs; o.status = out->status;
-    int rc = launch_env(h, WRSN_MODE_STEP, 0, h->dev.B, agent_id, action, auto_reset, nullptr, o);
-    if (rc) return rc;
-    if (out->obs) {
-        rc = launch_obs(h, h->dev.render_agent, out->obs);
-        if (h->timing && h->ev_ok) { (void)hipEventRecord(h->ev[4], h->stream); h->ev_obs = 1; }
-        return rc;
-    }
-    return WRSN_OK;
+    return launch_env(h, WRSN_MODE_STEP, 0, h->dev.B, agent_id, action, auto_reset, nullptr, o, out->obs);   // incl. the observations
 }
 
 int wrsn_set_obs_reuse(wrsn_t* h, int32_t on) {

@@ -2138,7 +2138,7 @@ __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, in
 template <int NPL, bool HEAVY>
 __global__ void __launch_bounds__(64, HEAVY ? WRSN_WAVES_PER_SIMD(NPL) : WRSN_WAVES_PER_SIMD_LEAN(NPL))
 wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id, const double* __restrict__ action, int auto_reset,
-                 int budget, long long epoch, int slots, const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff, int deadline) {
+                 int budget, long long epoch, int slots, const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff, int deadline, int block0) {
     extern __shared__ double smem[];
     // Block b of a step launch takes environment order[b]: the environments sorted by the work their WRSN.step still needs,
     // longest first (wrsn_estimate_kernel / wrsn_sort_kernel run in front of every step launch).  The duration of a WRSN.step is
@@ -2173,7 +2173,9 @@ wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* 
         //  finds it in flight, unstamped, and hands it over again)
         if (env < 0 || env >= dp->B || dp->heavy_epoch[env] != epoch || agent_id[env] == -2) return;
     } else if (!reset_call) {
-        env = dp->order[blockIdx.x];
+        // (`block0`: a step call may come as two launches over the two halves of the launch order -- see wrsn_step in wrsn_api.hip)
+        const int bidx = (int)blockIdx.x + block0;
+        env = dp->order[bidx];
         if (env < 0 || env >= dp->B) return;
         if (handoff == 1 && dp->heavy_epoch[env] == epoch) return;              // this call's heavy launch owns the environment
         if (budget > 0) {
@@ -2182,7 +2184,7 @@ wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* 
             // (`slots` packs three launch parameters: wave slots of the device, block at which the taper starts, blocks over which the
             //  budget falls to zero -- the floor of a quarter applies before that)
             const int n_slots = slots & 0xFFFF, t_start = (slots >> 16) & 0xFF, t_len = (slots >> 24) & 0xFF;
-            const int k = (int)blockIdx.x - t_start * (n_slots / 8);
+            const int k = bidx - t_start * (n_slots / 8);
 #ifndef WRSN_BUDGET_FLOOR
 #define WRSN_BUDGET_FLOOR 4
 #endif
@@ -2806,9 +2808,13 @@ WDEV int wrsn_wave_first(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // `reuse` (wrsn_set_obs_reuse): map 1 depends on node state only.  When no grid item ran since it was last rendered into this very row
 // (a WRSN.step that returns at the instant it was called -- 40 % of the steps of short episodes -- or the same charger asked twice),
 // the row still holds it: only maps 2..4, which depend on the asking charger, are written.
-__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs, int reuse) {
+// `row_map` (optional): block b renders environment row_map[map0 + b] -- a step call renders the half of the batch whose steps are short
+// (by the launch order) while the long half is still being stepped, and the rest afterwards.
+__global__ void __launch_bounds__(256, 4) wrsn_obs_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, float* __restrict__ obs, int reuse,
+                                                           const int32_t* __restrict__ row_map, int map0) {
     extern __shared__ double smem[];
-    const int env = blockIdx.x, tid = threadIdx.x;
+    const int env = row_map ? row_map[map0 + (int)blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
+    if (env < 0 || env >= d.B) return;
     const int aid = agent_id[env];
     if (aid < 0 || aid >= d.M) return;
     const WrsnEnvConst* ec = d.ec + env;
