@@ -226,7 +226,8 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     else if (split) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds_lean, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 1, dl, 0);                                      \
     else if (pipe) {                                                                                                    \
-        const int n_long = (nenv * h->pipe_long_pct / 100 + 63) & ~63;                                                 \
+        /* the long stage: at most as many environments as there are wave slots (its jobs should all start at once) */   \
+        int n_long = (nenv * h->pipe_long_pct / 100 + 63) & ~63; if (n_long > h->slots) n_long = h->slots & ~63; if (n_long < 64) n_long = 64; \
         const int b_short = budget > 0 ? (budget * h->pipe_short_pct / 100 > 64 ? budget * h->pipe_short_pct / 100 : 64) : 0; \
         hipStream_t s_short = h->pipe_swap ? h->stream : h->stream2, s_long = h->pipe_swap ? h->stream2 : h->stream;   \
         (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);              \
@@ -733,7 +734,11 @@ int wrsn_synth_network(uint64_t seed, int32_t n_node, int32_t n_target, double s
     const double bx = side / 2, by = side / 2;
     const double hop_lo = 0.62 * com, hop_hi = 0.995 * com, min_sep = 0.56 * com;
     std::vector<int> tips;
+    // Nodes next to the base station: 2..4 up to 512 nodes (the shipped scenarios have 2..3; networks of that size are unchanged), one more per
+    // 125 nodes above 256 (at most six) for the larger ones -- every packet of the network passes one of them, and with three of them a 1 000-node /
+    // 1 000-target network loses its first relay 40 s after the warm-up, which makes a benchmark of resets, not of the dynamics
     int n = 0, n_direct = 2 + rng.below(3);
+    if (n_node > 512) { n_direct += (n_node - 256) / 125; if (n_direct > 6) n_direct = 6; }   // (six fit the ring around the base station at the minimum separation)
     long tries = 0;
     while (n < n_node) {
         if (++tries > 4000000L) return fail(WRSN_ERR_ARG, "synthetic generator could not place the nodes (field too small?)");

@@ -10,8 +10,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 10 --cpu-seconds 0 --kernel-steps 5 --no-blocking-run"
+ARGS="--steps 40 --warmup 10 --cpu-seconds 0 --kernel-steps 5 --no-blocking-run ${BENCH_ARGS:-}"   # BENCH_ARGS / SUMMARY_ARGS: another configuration, e.g. "--nodes 1000 --targets 1000 --mcs 8" / "nodes=1000 targets=1000 chargers=8"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/write.log 2>&1
-python3 $ROOT/tools/profile_summarize.py $OUT $TAG
+python3 $ROOT/tools/profile_summarize.py $OUT $TAG ${SUMMARY_ARGS:-}
