@@ -57,7 +57,8 @@ def main():
     env = VecWRSN([synth_scenario(rank * B + e, N, N) for e in range(B)], None, M, auto_reset=True, step_budget=args.step_budget, device=str(dev),
                   reuse_obs=True)                             # BatchedIPPO only reads the state tensor (index_select / copies)
     algo = BatchedIPPO(dict(batch_size=args.batch_size, minibatch_size=args.minibatch_size, n_updates_per_iteration=args.updates), env,
-                       capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk, inference_dtype=args.inference_dtype)
+                       capacity=max(2 * args.batch_size, 4096), infer_chunk=args.infer_chunk, inference_dtype=args.inference_dtype,
+                       min_bucket=args.infer_chunk)           # ONE batch shape for every inference pass: MIOpen searches its convolution kernels per shape (seconds each)
     if args.warmup_iters > 0:
         algo.train(args.warmup_iters - 1)
         for k in algo.timers: algo.timers[k] = 0 if isinstance(algo.timers[k], int) else 0.0
