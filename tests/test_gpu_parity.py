@@ -833,3 +833,48 @@ def test_rollouts_continue_the_episodes_instead_of_restarting_them():
     with pytest.raises(RuntimeError):
         algo.batch_size = 10 ** 6; algo.roll_out(max_launches=1)
     env.close()
+
+
+def test_pipelined_step_calls_return_what_single_launches_return(monkeypatch):
+    """A step call that renders is issued as a two-stage pipeline over the launch order (wrsn_api.hip: the short half is stepped and
+    rendered on a second stream while the long half is stepped; the short half's work cap is 40 % of the budget).  Per environment the
+    requests -- agent, time, terminal, reward, observation -- are those of the single launch (WRSN_PIPE=0); only the call a request is
+    reported in may differ (another cap for a step in the short half).  Budgeted and blocking, 1 024 environments, whole episodes."""
+    torch = _torch()
+    from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
+    B, K = 1024, 30
+    uniq = [synth_scenario(15000 + u, 200, 200) for u in range(B)]
+    g = torch.Generator().manual_seed(9)
+    acts = torch.rand((K, B, 3), generator=g, dtype=torch.float64)
+
+    def run(pipe, budget):
+        monkeypatch.setenv("WRSN_PIPE", "1" if pipe else "0")
+        env = VecWRSN(uniq, None, 3, auto_reset=True, step_budget=budget)
+        r = env.reset(); env.synchronize()
+        n_given = np.zeros(B, dtype=int); hist = [[] for _ in range(B)]
+        for it in range(4 * K if budget else K):
+            fresh = (r["status"] != 4).cpu().numpy()
+            idx = torch.from_numpy(np.minimum(n_given, K - 1))
+            act = acts[idx, torch.arange(B)]
+            ids = r["agent_id"].clone()
+            ids[torch.from_numpy(fresh & (n_given >= K)).to(ids.device)] = -2     # this environment has had its K actions
+            r = env.step(ids, act); env.synchronize()
+            n_given += (fresh & (n_given < K)).astype(int)
+            st = r["status"].cpu().numpy(); a = r["agent_id"].cpu().numpy(); now = r["now"].cpu().numpy(); rew = r["reward"].cpu().numpy()
+            term = r["terminal"].cpu().numpy(); osum = r["state"].sum(dim=(1, 2, 3)).cpu().numpy()
+            for e in range(B):
+                if ids[e] != -2 and st[e] != 4:
+                    hist[e].append((int(st[e]), int(a[e]), float(now[e]), float(rew[e]), int(term[e]), float(osum[e]) if a[e] >= 0 else 0.0))
+        env.close()
+        return hist
+    for budget in (1250, 0):
+        h0 = run(False, budget); h1 = run(True, budget)
+        n_cmp = 0
+        for e in range(B):
+            n = min(len(h0[e]), len(h1[e]))
+            assert n >= K // 2, (budget, e, n)
+            for q0, q1 in zip(h0[e][:n], h1[e][:n]):
+                assert q0[:3] == q1[:3] and q0[4] == q1[4], (budget, e, q0, q1)
+                assert abs(q0[3] - q1[3]) <= 1e-7 * max(1.0, abs(q0[3])) and abs(q0[5] - q1[5]) <= 1e-6 * max(1.0, abs(q0[5])), (budget, e, q0, q1)
+            n_cmp += n
+        assert n_cmp > 20000
