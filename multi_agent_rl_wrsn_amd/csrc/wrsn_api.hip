@@ -65,7 +65,7 @@ struct wrsn_handle {
     hipStream_t stream;
     int npl;
     int scenario_set;
-    int lds_env, lds_lean, lds_obs;   // LDS bytes of an environment wave (full / lean variant of the step kernel), of an observation block
+    int lds_env, lds_obs;      // LDS bytes of an environment wave, of an observation block
     int cc_bound;              // largest WrsnEnvConst.conn_bound of the scenarios set so far (-> WrsnDev.CC)
     hipStream_t stream2;       // the heavy launch of a budgeted step call runs here, beside the lean launch on `stream`
     hipEvent_t ev_fork, ev_join; int ev2_ok;
@@ -78,7 +78,6 @@ struct wrsn_handle {
     int pipe_swap;             // 1: the short stage runs on the caller's stream (it is launched first), the long stage on the second one
     int pipe_short_pct;        // work cap of the short stage in per cent of the step budget (its stragglers go on in the next call)
     int pipe, pipe_long_pct;   // step calls that render as a two-stage pipeline over the launch order (WRSN_PIPE=0 disables); share of the long stage
-    int split;                 // budgeted steps as lean launch + concurrent heavy launch over the hand-off list (WRSN_SPLIT=1; diagnostic)
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
     int taper;                 // packed budget taper (start << 16 | length << 24), OR-ed into the `slots` kernel argument
     int obs_reuse;             // wrsn_set_obs_reuse: the caller keeps the observation rows the library wrote
@@ -126,15 +125,12 @@ int alloc_node_arrays(wrsn_handle* h, WrsnNodeArrays* a) {
 // LDS sizes, wave slots and the device copy of the descriptor; again whenever WrsnDev.CC changes
 int configure_launch(wrsn_handle* h) {
     WrsnDev& d = h->dev;
-    h->lds_env = wrsn_lds_bytes(d.NP, d.M, d.CC, 1);
-    h->lds_lean = wrsn_lds_bytes(d.NP, d.M, d.CC, 0);
+    h->lds_env = wrsn_lds_bytes(d.NP, d.M, d.CC);
     {   // wave slots of the step kernel on this device (registers and LDS decide): the budget taper of a launch starts behind the blocks
-        // that are resident from the first moment.  Budgeted calls launch the lean variant.
+        // that are resident from the first moment
         int per_cu = 0; hipError_t oe = hipErrorUnknown;
-        const bool lean = h->split != 0;
-        const int lds_b = (lean ? h->lds_lean : h->lds_env) + h->lds_pad;
-#define WRSN_OCC(NPL_) oe = lean ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<NPL_, false>, 64, (size_t)lds_b) \
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<NPL_, true>, 64, (size_t)lds_b)
+        const int lds_b = h->lds_env + h->lds_pad;
+#define WRSN_OCC(NPL_) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>, 64, (size_t)lds_b)
         WRSN_NPL_SWITCH(h->npl, WRSN_OCC, oe = hipErrorUnknown)
 #undef WRSN_OCC
         h->slots = h->cus * 8;
@@ -150,7 +146,7 @@ int launch_obs(wrsn_handle* h, const int32_t* agent_id, float* obs);
 // `obs_pipe` (step calls that render): the observations of this call are launched from here, interleaved with the step launches (below)
 int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agent_id, const double* action,
                int auto_reset, const uint8_t* mask, const WrsnStepOutDev& out, float* obs_pipe = nullptr) {
-    const int lds = h->lds_env + h->lds_pad, lds_lean = h->lds_lean + h->lds_pad;
+    const int lds = h->lds_env + h->lds_pad;
     const int reset_call = (mode == WRSN_MODE_RESET) ? 1 : 0;
     const int budget = (mode == WRSN_MODE_STEP) ? h->step_budget : 0;
     const int dl = (budget > 0 && h->bp2 > 0) ? h->deadline_ticks : 0;     // the sort kernel zeroes the launch stamp
@@ -159,30 +155,15 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     long long epoch = 0;
     if (mode == WRSN_MODE_STEP) epoch = ++h->epoch;            // every step call: a hand-off stamp names the one call whose heavy launch owns the environment
     const bool queue = (mode == WRSN_MODE_STEP) && h->deadline_ticks > 0;    // work-queue launch (wrsn_set_step_deadline)
-    const bool split = !queue && budget > 0 && h->split && h->ev2_ok;
     const bool timed = (mode == WRSN_MODE_STEP) && h->timing && h->ev_ok;
     if (timed) (void)hipEventRecord(h->ev[0], h->stream);
-    // A budgeted step call is two launches side by side.  On the second stream: the full variant of the step kernel over the environments the
-    // previous call's lean launch stopped in front of a heavy service (level BFS, routing rebuild, packet-exact second).  On the caller's
-    // stream: the lean variant (no code for those services, three waves per SIMD) over everybody else.  The heavy launch needs nothing of this
-    // call but the list, so it starts at once and the two overlap; the observation kernel waits for both.
-#define WRSN_HEAVY(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream2, (const WrsnDev*)h->d_dev, \
-                                           0, agent_id, action, 0, budget, epoch, 0, mask, out, 2, 0, 0)
-    if (split) {
-        (void)hipEventRecord(h->ev_fork, h->stream);
-        (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
-        WRSN_NPL_SWITCH(h->npl, WRSN_HEAVY, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
-        (void)hipEventRecord(h->ev_join, h->stream2);
-    }
-#undef WRSN_HEAVY
-    const int next_list = split ? (int)((epoch + 1) & 1) : -1;
     if (queue) {
         // latch + preset kernel, then one block per environment in this launch's cyclic order: the blocks that only start when the time slice
         // is over leave their environments alone
         hipLaunchKernelGGL(wrsn_latch_kernel, dim3((nenv + 255) / 256), dim3(256), 0, h->stream, h->dev, agent_id, action, out);
         if (timed) (void)hipEventRecord(h->ev[1], h->stream);
         const int qbudget = budget > 0 ? budget : (1 << 28);   // the deadline is looked at wherever a work budget is
-#define WRSN_QUEUE(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, 0, agent_id, action, \
+#define WRSN_QUEUE(NPL_) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, 0, agent_id, action, \
                                            auto_reset, qbudget, epoch, 0, mask, out, 3, h->deadline_ticks, 0)
         WRSN_NPL_SWITCH(h->npl, WRSN_QUEUE, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
 #undef WRSN_QUEUE
@@ -200,15 +181,14 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
     // the call -- while the long half (work-capped or slow steps, the tail of the launch) is still being stepped on the caller's stream;
     // only the observations of the long half are left for afterwards.  The step kernel is bound by instruction issue and latency and leaves
     // the HBM idle, the observation kernel is a 160 KB store stream per row: they overlap well.  Same blocks, same budgets, same results.
-    const bool pipe = obs_pipe && mode == WRSN_MODE_STEP && !split && h->pipe && h->ev2_ok && h->bp2 > 0 && nenv >= 512 && nenv == h->dev.B;
+    const bool pipe = obs_pipe && mode == WRSN_MODE_STEP && h->pipe && h->ev2_ok && h->bp2 > 0 && nenv >= 512 && nenv == h->dev.B;
     if (mode == WRSN_MODE_STEP && h->bp2 > 0) {
         // launch order of this call, longest job first (wrsn_estimate_kernel / wrsn_sort_kernel, wrsn_sim.h): two tiny launches
-        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2,
-                           split ? epoch : 0ll);
+        hipLaunchKernelGGL(wrsn_estimate_kernel, dim3((h->bp2 + WRSN_EST_THREADS - 1) / WRSN_EST_THREADS), dim3(WRSN_EST_THREADS), 0, h->stream, h->dev, agent_id, action, auto_reset, h->bp2);
         {
             const int kpt = h->bp2 / WRSN_SORT_THREADS;        // keys per thread of the sort workgroup (0, 1: plain network in LDS)
             const size_t lb = (size_t)wrsn_sort_lds_bytes();
-#define WRSN_SORT(K_) hipLaunchKernelGGL((wrsn_sort_kernel<K_>), dim3(1), dim3(WRSN_SORT_THREADS), lb, h->stream, h->dev, h->bp2, next_list)
+#define WRSN_SORT(K_) hipLaunchKernelGGL((wrsn_sort_kernel<K_>), dim3(1), dim3(WRSN_SORT_THREADS), lb, h->stream, h->dev, h->bp2)
             switch (kpt) {
             case 2: WRSN_SORT(2); break;
             case 4: WRSN_SORT(4); break;
@@ -219,22 +199,20 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
             }
 #undef WRSN_SORT
         }
-    } else if (split) HIPCHK(hipMemsetAsync(h->dev.heavy_n + next_list, 0, sizeof(int32_t), h->stream));
+    }
     if (timed) (void)hipEventRecord(h->ev[1], h->stream);
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
-    else if (split) hipLaunchKernelGGL((wrsn_step_kernel<NPL_, false>), grid, block, lds_lean, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 1, dl, 0);                                      \
     else if (pipe) {                                                                                                    \
         /* the long stage: at most as many environments as there are wave slots (its jobs should all start at once) */   \
         int n_long = (nenv * h->pipe_long_pct / 100 + 63) & ~63; if (n_long > h->slots) n_long = h->slots & ~63; if (n_long < 64) n_long = 64; \
         const int b_short = budget > 0 ? (budget * h->pipe_short_pct / 100 > 64 ? budget * h->pipe_short_pct / 100 : 64) : 0; \
         hipStream_t s_short = h->pipe_swap ? h->stream : h->stream2, s_long = h->pipe_swap ? h->stream2 : h->stream;   \
         (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);              \
-        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(nenv - n_long), block, lds, s_short, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(nenv - n_long), block, lds, s_short, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                            auto_reset, b_short, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, n_long);                                 \
         hipLaunchKernelGGL(wrsn_obs_kernel, dim3(nenv - n_long), dim3(256), h->lds_obs, s_short, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, n_long); \
-        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), dim3(n_long), block, lds, s_long, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(n_long), block, lds, s_long, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                            auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0);                                       \
         if (timed && !h->pipe_swap) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); } \
         hipLaunchKernelGGL(wrsn_obs_kernel, dim3(n_long), dim3(256), h->lds_obs, s_long, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, 0); \
@@ -242,7 +220,7 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
         (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);                                                            \
         if (timed && h->pipe_swap) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); } \
     }                                                                                                                  \
-    else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, true>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+    else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                             auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0)
     WRSN_NPL_SWITCH(h->npl, WRSN_LAUNCH, return fail(WRSN_ERR_ARG, "unsupported nodes-per-lane"))
 #undef WRSN_LAUNCH
@@ -252,7 +230,6 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
         return 0;
     }
     if (timed) (void)hipEventRecord(h->ev[2], h->stream);
-    if (split) (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);   // whatever follows on the caller's stream sees both launches
     if (timed) { (void)hipEventRecord(h->ev[3], h->stream); h->ev_obs = 0; h->ev_rec = 1; }
     HIPCHK(hipGetLastError());
     if (obs_pipe) {
@@ -315,9 +292,6 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     if (!guard_.ok) return fail(WRSN_ERR_HIP, "hipSetDevice failed");
     wrsn_handle* h = new wrsn_handle();
     h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->deadline_ticks = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0; h->ev_rec = 0;
-    // WRSN_SPLIT=1: budgeted calls as lean launch + concurrent heavy launch (measured in r03, profiles/r03_split_experiment.log: slower than the
-    // one full launch at every budget -- the hand-off costs an environment the rest of its launch; kept as a diagnostic, parity-tested)
-    { const char* e = std::getenv("WRSN_SPLIT"); h->split = (e && *e == '1') ? 1 : 0; }
     { const char* e = std::getenv("WRSN_PIPE"); h->pipe = (e && *e == '0') ? 0 : 1; }
     { const char* e = std::getenv("WRSN_PIPE_SWAP"); h->pipe_swap = (e && *e == '1') ? 1 : 0; }
     { const char* e = std::getenv("WRSN_PIPE_SHORT_PCT"); h->pipe_short_pct = e ? std::atoi(e) : 40; if (h->pipe_short_pct < 5 || h->pipe_short_pct > 100) h->pipe_short_pct = 40; }
@@ -387,9 +361,6 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
         if ((rc = dalloc(h, &d.launch_t0, 1))) break;
         if ((rc = dalloc(h, &d.render_agent, B))) break;
         if ((rc = dalloc(h, &d.row_state, B))) break;
-        if ((rc = dalloc(h, &d.heavy_list, 2 * B))) break;
-        if ((rc = dalloc(h, &d.heavy_n, 2))) break;
-        if ((rc = dalloc(h, &d.heavy_epoch, B))) break;
         if ((rc = dalloc(h, &d.queue, 8 + 64))) break;
         if ((rc = dalloc(h, &d.qskip, B))) break;
         if ((rc = dalloc(h, &h->d_dev, 1))) break;
@@ -534,10 +505,6 @@ int wrsn_kernel_times(wrsn_t* h, float* ms) {
 int wrsn_set_step_budget(wrsn_t* h, int32_t work_units) {
     if (!h || work_units < 0) return fail(WRSN_ERR_ARG, "bad step budget");
     WRSN_ON_DEVICE(h);
-    if ((work_units > 0) != (h->step_budget > 0)) {            // (re)entering budgeted mode: no environment is listed yet
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipMemset(h->dev.heavy_n, 0, 2 * sizeof(int32_t)));
-    }
     h->step_budget = work_units;
     return WRSN_OK;
 }

@@ -254,11 +254,11 @@ WDEV void wrsn_lds_gather8_b64(const double* base, const int (&idx)[8], double (
 }
 #endif
 
-// HEAVY = false builds the lean variant of the simulator for the common path of a step: it holds no code for the three
-// rare, register-hungry services -- the level BFS after a death (set_levels), the routing-cache rebuild (rebuild_cache)
-// and the packet-exact second (exact_walk).  When a grid item needs one of them the lean variant stops in front of that
-// item exactly like an environment that ran out of its launch budget (`need_heavy`), and the full variant goes on with
-// it in a second, small launch (wrsn_step_kernel<NPL, true> over the hand-off list).
+// Sim<NPL, true> holds everything; Sim<NPL, false> -- the simulator of the step kernel's common path -- has no code for the three rare,
+// register-hungry services: the level BFS after a death (set_levels), the routing-cache rebuild (rebuild_cache) and the packet-exact
+// second (exact_walk).  When a grid item needs one of them it stops in front of that item exactly like an environment that ran out
+// of its launch budget (`need_heavy`), the step kernel stores the environment, calls wrsn_step_env_full -- a NOINLINE device function
+// with the full simulator, which loads the environment, runs that one item and suspends (or finishes the step) -- and goes on.
 template <int NPL, bool HEAVY = true>
 struct Sim {
     // identity / geometry.  Pointers are not kept as members: they are derived on demand from the device descriptor
@@ -286,8 +286,8 @@ struct Sim {
     long long t_deadline;                                    // wall clock at which this launch stops taking new grid items (0 = none); wave-uniform
     long long t_exact;                                       // ... at which it stops beginning packet-exact seconds (time-sliced launches; 0 = none)
     int fit_dirty, map1_valid;                               // a grid service ran since last_minfit was evaluated / map 1 of the observation still stands (wave-uniform)
-    int need_heavy;                                          // lean variant: the next grid item needs a service only the full variant has; full variant: a
-                                                             // packet-exact second was put off because the time-sliced launch is about to end
+    int need_heavy;                                          // HEAVY = false: the next grid item needs a service this variant has no code for (1); either
+                                                             // variant: a packet-exact second was put off because the time-sliced launch is about to end (2)
     int n_items;                                             // grid items completed in this visit (wave-uniform)
     double last_minfit;
     WRSN_PROF_DECL
@@ -319,13 +319,13 @@ struct Sim {
     WDEV const U4 WRSN_GLOBAL_AS* TCP() const { return wrsn_global((const U4*)(dp->tcp + (size_t)env * dp->TP * 4)); }
     WDEV double WRSN_GLOBAL_AS* RING() const { return wrsn_global((use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP); }
     WDEV double WRSN_GLOBAL_AS* LOGBUF() const { return wrsn_global((use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP); }
-    // ---- LDS carve-up (must match wrsn_lds_bytes).  The lean variant never touches the cached receivers: they stay in HBM.
+    // ---- LDS carve-up (must match wrsn_lds_bytes)
     WDEV double* SRR() const { return smem_; }
     WDEV double* SU() const { return smem_ + NP; }
     WDEV int32_t* SLS() const { return (int32_t*)(smem_ + 3 * NP); }
-    WDEV int32_t* SRCV() const { static_assert(HEAVY, "cached receivers are staged by the full variant only"); return SLS() + NP; }
+    WDEV int32_t* SRCV() const { return SLS() + NP; }
     // time-parallel steady batch: float CS per node, records / per-second table of the (few) nodes being charged
-    WDEV float* SCSF() const { return (float*)(smem_ + 3 * NP + (HEAVY ? NP : NP / 2)); }
+    WDEV float* SCSF() const { return (float*)(smem_ + 4 * NP); }
     WDEV double* SCHGREC() const { return (double*)SCSF() + NP / 2; }                    // [CHG_MAX][8]: E, d1, d2, rr, node, E_final, CS
     WDEV double* SCHGTAB() const { return SCHGREC() + 8 * kChgMax; }                 // [CHG_MAX][64] energy at the reward instant of second s
     WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(SCHGTAB() + 64 * kChgMax); }
@@ -455,7 +455,7 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane, ii = i < N ? i : 0;   // the padding up to NP is never read nor written back
             E[j] = gE[ii]; CS[j] = gCS[ii]; d1[j] = gd1[ii]; d2[j] = gd2[ii]; rr[j] = gRR[ii]; lsw[j] = gls[ii];
-            rcw[j] = HEAVY ? grcv[ii] : -1;
+            rcw[j] = grcv[ii];
         }
         const WrsnEnvDyn* dy = a.dyn + env;
         // charger / process records and connected-node lists: lane w takes 8-byte word w, w + 64, ... (fixed trip counts for the largest
@@ -492,7 +492,7 @@ struct Sim {
             E[j] = real ? E[j] : 0.0; CS[j] = real ? CS[j] : 0.0; d1[j] = real ? d1[j] : 0.0; d2[j] = real ? d2[j] : 0.0;
             SRR()[i] = real ? rr[j] : 0.0;
             const int ls = real ? lsw[j] : 0; SLS()[i] = ls;
-            if constexpr (HEAVY) SRCV()[i] = real ? rcw[j] : -1;
+            SRCV()[i] = real ? rcw[j] : -1;
             am |= (unsigned)(ls & 1) << j;
         }
         uint64_t* la = (uint64_t*)SAG(); uint64_t* lt = (uint64_t*)STH();
@@ -521,9 +521,7 @@ struct Sim {
                 if (dirty & 4) gCS[i] = CS[j];
                 if (dirty & 1) {
                     gd1[i] = d1[j]; gd2[i] = d2[j];
-                    // (the lean variant never changes the routing cache; it writes it only when an auto-reset restores the snapshot, and
-                    //  then the receivers, which it does not stage, go from the snapshot to the live array directly)
-                    if constexpr (HEAVY) grcv[i] = SRCV()[i]; else grcv[i] = wrsn_global(dp->snap.rcv + nb)[i];
+                    grcv[i] = SRCV()[i];
                 }
                 if (dirty & 2) gls[i] = SLS()[i];
             }
@@ -1030,7 +1028,7 @@ struct Sim {
             if (!HEAVY && !fast) { need_heavy = 1; return; }  // nothing was touched: the full variant takes this item again
             // time-sliced launch about to end: a packet-exact second is not begun (unless nothing else was done in this visit); the
             // environment stops in front of the item and the next launch, in which it is among the first, takes it again
-            if (!fast && t_exact != 0 && n_items > 0 && (long long)wall_clock64() > t_exact) { need_heavy = 1; return; }
+            if (!fast && t_exact != 0 && n_items > 0 && (long long)wall_clock64() > t_exact) { need_heavy = 2; return; }
         }
         if (fast) {
             if (any_rr) {
@@ -2036,7 +2034,7 @@ struct Sim {
             }
             __syncthreads();
             WRSN_P4_MARK(r4_) if (req == REQ_GRID) { WRSN_P4_SPAN(14, r3_, r4_) } else if (req == REQ_PRECHECK) { WRSN_P4_SPAN(12, r3_, r4_) } else { WRSN_P4_SPAN(13, r3_, r4_) }
-            if (need_heavy) { suspended = true; break; }     // lean: the full variant goes on in front of this grid item; full: put off to the next launch
+            if (need_heavy) { suspended = true; break; }     // a packet-exact second put off to the next (time-sliced) launch
         }
         if (!stopped && !suspended) err = -10;               // the service loop ran out: the environment is stuck, report it (status < 0)
         __syncthreads();
@@ -2052,15 +2050,18 @@ struct Sim {
 //                     restores the snapshot into d.live and emits the reset request instead        (WRSN.py:66-75)
 // Two kernels so that the event machine and every O(N) routine are instantiated once per code object.
 // two waves per SIMD (256 registers) for up to 256 nodes: the event machine is latency-bound, a second wave hides it
-// The full variant keeps 256 registers (two waves per SIMD up to 256 nodes, one above); the lean variant -- the common path of a budgeted
-// step, without the level BFS / routing rebuild / packet-exact second -- is compiled for THREE waves per SIMD (168 registers, and an
-// LDS footprint of at most 13.6 KB so that twelve environments share a CU): the event machine and the grid loop are latency-bound serial
-// code, and a third resident wave hides what two leave idle (SQ_WAIT_ANY 49 % at two waves).
+// two waves per SIMD (256 registers) for up to 256 nodes, one above.  (r03 measured three waves per SIMD at 168 registers, with and
+// without the rare services in the code object: slower, the common path spills there -- DESIGN.md 4.1)
 #ifndef WRSN_WAVES_PER_SIMD
 #define WRSN_WAVES_PER_SIMD(NPL_) ((NPL_) <= 4 ? 2 : 1)
 #endif
-#ifndef WRSN_WAVES_PER_SIMD_LEAN
-#define WRSN_WAVES_PER_SIMD_LEAN(NPL_) ((NPL_) <= 4 ? 3 : 1)
+// WRSN_KERNEL_INLINE = true (the product): the step kernel is ONE code object with the rare services inlined.  false builds the r03
+// experiment -- the common-path simulator Sim<NPL, false> in the kernel, the full one behind a noinline call for the one grid item that
+// needs it (wrsn_step_env_full): measured 2 x slower (1.03 ms against 0.51 ms per launch, profiles/r03_ab_load_eventmachine.log), as was
+// the first form of it (the three services as noinline functions taking the node registers through memory: 1.24 ms -- the register
+// allocator puts the spills of a call at the head of the enclosing hot region, not at the rare call site).  tools/ab_build.sh.
+#ifndef WRSN_KERNEL_INLINE
+#define WRSN_KERNEL_INLINE true
 #endif
 template <int NPL>
 __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kernel(const WrsnDev* __restrict__ dp, int env0) {
@@ -2068,7 +2069,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     const int env = env0 + blockIdx.x;
     const int lane = threadIdx.x;
     if (env >= dp->B) return;
-    Sim<NPL, true> s;
+    Sim<NPL, true> s;                                        // (one-off: the full simulator, everything inline)
     s.bind(dp, env, lane, smem);
     const WrsnEnvConst* ec = s.EC();
     // NetworkIO.makeNetwork + Node.__init__ (Node.py:12-43) + t = 0 process start-up
@@ -2126,17 +2127,26 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     s.store(dp->snap, 0, 0);
 }
 
-// `handoff`: 0 = the only environment launch of this call (full variant: blocking steps, resets);
-//            1 = lean launch of a budgeted step call: an environment that meets a heavy service is stamped and listed for the NEXT call's
-//                heavy launch; environments stamped for THIS call are left alone (the heavy launch beside this one owns them);
-//            2 = heavy launch (full variant) over the list the previous call's lean launch wrote: block b takes its b-th entry.
+// `handoff`: 0 = one block per environment in the launch order (`block0`: the launch covers blocks block0 .. of it); 3 = time-sliced launch.
+//            4 = (wrsn_step_env_full only) go on with the step in flight of this environment, whatever the caller's rows say.
+// Returns (work units spent << 1) | 1 when the HEAVY = false simulator stopped in front of a grid item it has no code for.
 template <int NPL, bool HEAVY>
-__device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
-                                              const double* __restrict__ action, int auto_reset, int budget, long long epoch,
-                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem, long long t_end);
+__device__ __forceinline__ int wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
+                                             const double* __restrict__ action, int auto_reset, int budget, long long epoch,
+                                             const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem, long long t_end);
+
+// The full simulator, out of line: one grid item of the step in flight of `env` (budget 1: the item in front of which the common-path
+// simulator stopped -- level BFS, routing rebuild, packet-exact second -- and whatever charger events follow it up to the next grid
+// service), then the environment is stored again, suspended or finished.  Its own register allocation and its own spills; the call
+// sits where the caller holds next to nothing in registers.
+template <int NPL>
+__device__ __noinline__ void wrsn_step_env_full(const WrsnDev* dp, int env, long long epoch, WrsnStepOutDev out) {
+    extern __shared__ double smem[];
+    (void)wrsn_step_env<NPL, true>(dp, env, 0, nullptr, nullptr, 0, 1, epoch, nullptr, out, 4, 0, smem, 0);
+}
 
 template <int NPL, bool HEAVY>
-__global__ void __launch_bounds__(64, HEAVY ? WRSN_WAVES_PER_SIMD(NPL) : WRSN_WAVES_PER_SIMD_LEAN(NPL))
+__global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL))
 wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* __restrict__ agent_id, const double* __restrict__ action, int auto_reset,
                  int budget, long long epoch, int slots, const uint8_t* __restrict__ env_mask, WrsnStepOutDev out, int handoff, int deadline, int block0) {
     extern __shared__ double smem[];
@@ -2166,18 +2176,11 @@ wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* 
         env = dp->queue[1] + (int)blockIdx.x; env = env >= B ? env - B : env;
         if (dp->qskip[env]) return;
         t_slice_end = t_end;
-    } else if (handoff == 2) {
-        if ((int)blockIdx.x >= dp->heavy_n[(int)(epoch & 1)]) return;
-        env = dp->heavy_list[(size_t)(epoch & 1) * dp->B + blockIdx.x];
-        // (a reset between the two calls takes the stamp away; a row the caller marks -2 is left alone -- the lean launch of the next call
-        //  finds it in flight, unstamped, and hands it over again)
-        if (env < 0 || env >= dp->B || dp->heavy_epoch[env] != epoch || agent_id[env] == -2) return;
     } else if (!reset_call) {
         // (`block0`: a step call may come as two launches over the two halves of the launch order -- see wrsn_step in wrsn_api.hip)
         const int bidx = (int)blockIdx.x + block0;
         env = dp->order[bidx];
         if (env < 0 || env >= dp->B) return;
-        if (handoff == 1 && dp->heavy_epoch[env] == epoch) return;              // this call's heavy launch owns the environment
         if (budget > 0) {
             // blocks are dispatched in index order: a block far behind the first `slots` ones starts late, and what it is
             // allowed to spend shrinks accordingly so that the launch does not wait for late long jobs
@@ -2192,32 +2195,41 @@ wrsn_step_kernel(const WrsnDev* __restrict__ dp, int reset_call, const int32_t* 
         }
     }
     if (env < 0 || env >= dp->B) return;
-    wrsn_step_env<NPL, HEAVY>(dp, env, reset_call, agent_id, action, auto_reset, budget, epoch, env_mask, out, handoff, deadline, smem, t_slice_end);   // the one call site
+    for (int pass = 0; pass < 256; ++pass) {
+        const int r = wrsn_step_env<NPL, HEAVY>(dp, env, reset_call, agent_id, action, auto_reset, budget, epoch, env_mask, out, handoff, deadline, smem, t_slice_end);   // the one call site
+        if (HEAVY || !(r & 1)) break;
+        // the common-path simulator stopped in front of a rare service: the full simulator takes that one item, then this one goes on
+        __syncthreads();
+        wrsn_step_env_full<NPL>(dp, env, epoch, out);
+        __syncthreads();
+        if (wu(dp->live.dyn[env].susp) == 0) break;        // the step ended in there: its request is written
+        if (budget > 0) { budget -= (r >> 1) + 64; if (budget < 16) budget = 16; }
+    }
 }
 
 template <int NPL, bool HEAVY>
-__device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
-                                              const double* __restrict__ action, int auto_reset, int budget, long long epoch,
-                                              const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem, long long t_end) {
+__device__ __forceinline__ int wrsn_step_env(const WrsnDev* __restrict__ dp, int env, int reset_call, const int32_t* __restrict__ agent_id,
+                                             const double* __restrict__ action, int auto_reset, int budget, long long epoch,
+                                             const uint8_t* __restrict__ env_mask, const WrsnStepOutDev& out, int handoff, int deadline, double* smem, long long t_end) {
     const int lane = threadIdx.x;
     bool do_reset = reset_call != 0;
     // a row nobody handles in this launch is not rendered and none of its outputs is touched
-    if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
+    if (reset_call && env_mask && env_mask[env] == 0) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return 0; }
     int aid = -1, resume = 0;
     const double* act_src = action + (size_t)env * 3;
-    if (handoff == 2) resume = 1;                          // handed over by the previous call's lean launch: the step is in flight
-    else if (handoff == 3) {                               // work-queue launch: the action waits in the latch, the caller's row is not looked at
+    if (handoff == 4) resume = 1;                          // the full simulator called for one item of the step in flight
+    else if (handoff == 3) {                               // time-sliced launch: the action waits in the latch, the caller's row is not looked at
         const WrsnEnvDyn* dy = dp->live.dyn + env;
         resume = dy->susp;
-        if (!resume) { if (!dy->lat_valid) return; aid = dy->lat_agent; act_src = dy->lat_action; }
+        if (!resume) { if (!dy->lat_valid) return 0; aid = dy->lat_agent; act_src = dy->lat_action; }
         if (auto_reset && dy->terminal_pending) do_reset = true;
     } else if (!reset_call) {
         aid = agent_id[env];
-        if (aid == -2) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return; }
+        if (aid == -2) { if (lane == 0) { dp->render_agent[env] = -1; dp->row_state[env] = 0; } return 0; }
         resume = dp->live.dyn[env].susp;                   // a step in flight goes on; agent_id / action are not looked at
         if (auto_reset && dp->live.dyn[env].terminal_pending) do_reset = true;
     }
-    if (reset_call && lane == 0) { dp->heavy_epoch[env] = 0; dp->live.dyn[env].lat_valid = 0; }   // a reset environment is nobody's hand-off any more, and holds no action
+    if (reset_call && lane == 0) dp->live.dyn[env].lat_valid = 0;   // a reset environment holds no latched action
     Sim<NPL, HEAVY> s;
     s.bind(dp, env, lane, smem);
     if (handoff == 3) { s.t_deadline = t_end; s.t_exact = t_end - (deadline / 2 < WRSN_EXACT_MARGIN ? deadline / 2 : WRSN_EXACT_MARGIN); }   // the time-sliced launch stamped its start itself
@@ -2322,11 +2334,6 @@ __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, in
             if (out.now) out.now[env] = s.now;
             if (out.status) out.status[env] = (s.err != 0) ? -4 : 4;
             dp->render_agent[env] = -1; dp->row_state[env] = 3;
-            if (!HEAVY && s.need_heavy) {                    // the heavy launch of the next call goes on with it
-                const int nl = (int)((epoch + 1) & 1);
-                const int pos = atomicAdd(&dp->heavy_n[nl], 1);
-                dp->heavy_list[(size_t)nl * dp->B + pos] = env; dp->heavy_epoch[env] = epoch + 1;
-            }
         }
         if (lane == 0 && !susp) {
             int agent = -1, status = st0; double reward = 0.0;
@@ -2367,6 +2374,7 @@ __device__ __forceinline__ void wrsn_step_env(const WrsnDev* __restrict__ dp, in
     if (lane == 0) { dp->counters[(size_t)env * 24 + 22] = wt0_; dp->counters[(size_t)env * 24 + 23] = wall_clock64(); }
 #endif
 #endif
+    return (!HEAVY && susp && s.need_heavy == 1) ? ((s.work << 1) | 1) : 0;
 }
 
 // ------------------------------------------------------------------ work-queue launches: latch the actions, preset the rows
@@ -2413,7 +2421,7 @@ __global__ void __launch_bounds__(256) wrsn_latch_kernel(WrsnDev d, const int32_
 // is a pure function of the environment states, not of timing.
 #define WRSN_EST_THREADS 64      // one wave per workgroup: the ~45 scattered cache lines an environment costs are spread over as many CUs as possible
 __global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev d, const int32_t* __restrict__ agent_id, const double* __restrict__ action,
-                                                            int auto_reset, int BP2, long long heavy_call) {
+                                                            int auto_reset, int BP2) {
     const int e = blockIdx.x * WRSN_EST_THREADS + threadIdx.x;
     if (e >= BP2) return;
     if (e >= d.B) { d.order_key[e] = 0xFFFFFFFFu; return; }  // padding sorts to the end
@@ -2432,8 +2440,7 @@ __global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev
         st[m] = a->status; td[m] = a->t_done; lx[m] = a->loc[0]; ly[m] = a->loc[1];
     }
     double w = 0.0;
-    // (heavy_call != 0: a budgeted call -- environments stamped for its heavy launch are skipped by the lean launch: no work, sorted to the end)
-    if (aid != -2 && !(auto_reset && term_p) && !(heavy_call != 0 && d.heavy_epoch[e] == heavy_call)) {
+    if (aid != -2 && !(auto_reset && term_p)) {
         double t_first = 1.0e30;
 #pragma unroll
         for (int m = 0; m < WRSN_MAX_MC; ++m) {
@@ -2469,16 +2476,13 @@ __global__ void __launch_bounds__(WRSN_EST_THREADS) wrsn_estimate_kernel(WrsnDev
 #define WRSN_ORDER_BUCKETS 2048
 static inline int wrsn_sort_lds_bytes() { return (WRSN_ORDER_BUCKETS + 1 + WRSN_SORT_THREADS / 64 + 1) * 4; }
 template <int K>
-__global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d, int BP2, int next_list) {
+__global__ void __launch_bounds__(WRSN_SORT_THREADS) wrsn_sort_kernel(WrsnDev d, int BP2) {
     extern __shared__ double smem[];
     constexpr int NBK = WRSN_ORDER_BUCKETS, T = WRSN_SORT_THREADS, NW = T / 64, PER = (NBK + 1 + T - 1) / T;
     int* hist = (int*)smem; int* wsum = hist + NBK + 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i <= NBK; i += T) hist[i] = 0;
-    if (tid == 0) {
-        *d.launch_t0 = 0;                                    // the step launch behind this kernel stamps its start (wrsn_set_step_deadline)
-        if (next_list >= 0) d.heavy_n[next_list] = 0;        // the hand-off list the lean launch behind this kernel fills for the next call
-    }
+    if (tid == 0) *d.launch_t0 = 0;
     __syncthreads();
     unsigned key[K]; int bk[K];
 #pragma unroll

@@ -112,13 +112,6 @@ struct WrsnDev {
     int64_t *counters;                // [4]
     uint32_t *order_key;              // [BP2]  launch order of a step call, longest job first: (0xFFFF - estimated work) << 13 | environment,
     int32_t *order;                   // [BP2]  sorted ascending; order[b] = environment of block b (BP2 = B rounded up to a power of two)
-    // Hand-off of a budgeted step call (wrsn_set_step_budget): the lean variant of the step kernel holds no code for the level BFS, the routing
-    // rebuild and the packet-exact second; an environment that meets one of them in call k stops in front of it, is appended to list
-    // (k + 1) & 1 and stamped heavy_epoch = k + 1.  Call k + 1 runs the full variant over that list on a second stream, BESIDE its lean
-    // launch, which leaves every environment stamped k + 1 alone.
-    int32_t *heavy_list;              // [2][B]
-    int32_t *heavy_n;                 // [2]
-    long long *heavy_epoch;           // [B]    step call whose heavy launch owns the environment (0: none)
     int32_t *row_state;               // [B]    what the last environment launch did with the row: 0 left untouched, 1 WRSN.step completed
                                       //        (fresh request), 2 reset / auto-reset request, 3 step still in flight, 4 terminal return
     long long *launch_t0;             // [1]    wall clock (100 MHz) at which the first wave of the current step launch started; zeroed by the
@@ -137,14 +130,13 @@ struct WrsnStepOutDev {
 
 #define WRSN_LDS_SCALAR_BYTES 64
 // nodes under charge handled by the time-parallel steady batch (more fall back to the per-second path): four up to 256 nodes -- three
-// chargers with one or two nodes in range each -- so that three environments per SIMD fit the LDS; eight up to 512, six above (three
+// chargers with one or two nodes in range each --, eight up to 512, six above (three
 // environments of 1 024 nodes x 8 chargers then fit the 160 KB of a CU instead of two)
 #define WRSN_CHG_MAX(NP_) ((NP_) > 512 ? 6 : ((NP_) > 256 ? 8 : 4))
-// LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h).  `heavy`: the full variant also stages the cached receivers.
-static inline int wrsn_lds_bytes(int NP, int M, int CC, int heavy) {
+// LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h)
+static inline int wrsn_lds_bytes(int NP, int M, int CC) {
     int b = 0;
-    b += 3 * NP * 8 + NP * 4;                         // charging rate, 2 scratch arrays, level/alive words
-    if (heavy) b += NP * 4;                           // cached receivers
+    b += 3 * NP * 8 + 2 * NP * 4;                     // charging rate, 2 scratch arrays, level/alive words, cached receivers
     b += M * (int)sizeof(WrsnAgent) + 2 * M * (int)sizeof(WrsnThread);
     b += (M + 1) * (8 + 8);                           // condition times / seqs
     b += 4 * M * CC * 8;                              // connected-node positions (x, y), reward-entry rates and accumulators

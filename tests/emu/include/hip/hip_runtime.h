@@ -23,6 +23,8 @@
 #define __shared__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define __noinline__ __attribute__((noinline))
+inline void __threadfence() {}
 #define WRSN_GLOBAL_AS                       /* one address space here */
 #define WRSN_LD_U4_DEFINED
 template <typename T> inline T wrsn_ld_u4(const T* p) { return *p; }

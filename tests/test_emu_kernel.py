@@ -528,50 +528,6 @@ def test_emulated_observation_reuse_is_bit_identical():
     assert zero_time >= 3
 
 
-def test_emulated_split_launches_return_the_same_requests(monkeypatch):
-    """WRSN_SPLIT=1 (diagnostic): a budgeted step call as two launches -- the lean variant of the step kernel over everybody, and the
-    full variant over the environments the PREVIOUS call's lean launch stopped in front of a heavy service (level BFS, routing rebuild,
-    packet-exact second; hand-off stamp + list, wrsn_sim.h).  With auto-reset, over whole episodes with node deaths: per environment the
-    sequence of requests is the one of the single full launch (only the call a request is reported in differs), including the rows a
-    caller marks -2 while their step is handed off."""
-    from multi_agent_rl_wrsn_amd import DEFAULT_MC_SPEC, synth_scenario
-    B, M, G = 3, 2, 12
-    scs = [synth_scenario(300 + e, 70, 60) for e in range(B)]
-
-    def run(split, calls, pause):
-        monkeypatch.setenv("WRSN_SPLIT", "1" if split else "0")
-        ev = _emu(scs, DEFAULT_MC_SPEC, M, map_size=G)
-        ev.h.set_step_budget(60)
-        ev.reset()
-        hist = [[] for _ in range(B)]; n_flight = 0
-        for it in range(calls):
-            ids = ev.agent_id.copy()
-            act = np.stack([np.random.RandomState(1000 * e + len(hist[e])).rand(3) for e in range(B)])
-            if pause and it % 7 == 3:
-                ids[1] = -2                                   # left alone for this call, whatever state its step is in
-            keep = (ev.agent_id[1], ev.now[1], ev.reward[1], ev.status[1])
-            ev.step(ids, act, auto_reset=True)
-            if ids[1] == -2:
-                assert (ev.agent_id[1], ev.now[1], ev.reward[1], ev.status[1]) == keep
-            for e in range(B):
-                if ids[e] == -2:
-                    continue
-                if ev.status[e] == 4:
-                    n_flight += 1
-                else:
-                    hist[e].append((int(ev.status[e]), int(ev.agent_id[e]), float(ev.now[e]), float(ev.reward[e]), int(ev.terminal[e])))
-        return hist, n_flight
-    full, _ = run(False, 260, False)
-    for pause in (False, True):
-        split, n_flight = run(True, 260, pause)
-        assert n_flight > 50
-        for e in range(B):
-            n = min(len(full[e]), len(split[e]))
-            assert n >= 20 and sum(q[4] for q in split[e][:n]) >= 1          # whole episodes, terminal returns included
-            for a, b in zip(full[e][:n], split[e][:n]):
-                assert a[:3] == b[:3] and a[4] == b[4] and abs(a[3] - b[3]) <= 1e-9 * max(1.0, abs(a[3])), (e, a, b)
-
-
 def test_emulated_work_queue_launches_return_the_same_requests():
     """wrsn_set_step_deadline = work-queue launches: persistent waves hand the environments out among themselves in a cyclic order until
     the common deadline of the launch; an environment nobody reaches is not touched -- its action waits in the latch over as many launches
