@@ -67,15 +67,15 @@ struct wrsn_handle {
     int scenario_set;
     int lds_env, lds_obs;      // LDS bytes of an environment wave, of an observation block
     int cc_bound;              // largest WrsnEnvConst.conn_bound of the scenarios set so far (-> WrsnDev.CC)
-    hipStream_t stream2;       // the heavy launch of a budgeted step call runs here, beside the lean launch on `stream`
-    hipEvent_t ev_fork, ev_join; int ev2_ok;
+    hipStream_t stream2, stream3;   // the later stages of a pipelined step call run here, beside the first one on `stream`
+    hipEvent_t ev_fork, ev_join, ev_join3; int ev2_ok;
     int cus;                   // compute units of the device
     int slots;                 // wave slots of the device for the step kernel (CUs x resident waves per CU): launch-order dependent budgets
     int waves_per_cu;          // what the occupancy query said for this handle's step kernel (diagnostic)
     long long epoch;           // counter of wrsn_step calls (its parity selects the hand-off list a budgeted call reads / writes)
     int step_budget;           // work units one wrsn_step launch may spend per environment, 0 = run every step to its end
     int deadline_ticks;        // wrsn_set_step_deadline in 100 MHz wall-clock ticks, 0 = none
-    int pipe_swap;             // 1: the short stage runs on the caller's stream (it is launched first), the long stage on the second one
+    int pipe_mid_pct;          // share of the long half that stays on the caller's stream (the rest: third stream); 100 = two stages
     int pipe_short_pct;        // work cap of the short stage in per cent of the step budget (its stragglers go on in the next call)
     int pipe, pipe_long_pct;   // step calls that render as a two-stage pipeline over the launch order (WRSN_PIPE=0 disables); share of the long stage
     int lds_pad;               // extra LDS bytes per environment wave (occupancy experiments); diagnostic
@@ -204,21 +204,29 @@ int launch_env(wrsn_handle* h, int mode, int env0, int nenv, const int32_t* agen
 #define WRSN_LAUNCH(NPL_)                                                                                              \
     if (mode == WRSN_MODE_WARMUP) hipLaunchKernelGGL(wrsn_warmup_kernel<NPL_>, grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, env0);  \
     else if (pipe) {                                                                                                    \
-        /* the long stage: at most as many environments as there are wave slots (its jobs should all start at once) */   \
-        int n_long = (nenv * h->pipe_long_pct / 100 + 63) & ~63; if (n_long > h->slots) n_long = h->slots & ~63; if (n_long < 64) n_long = 64; \
+        /* stages over the launch order: [0, n1) the longest jobs (caller's stream), [n1, n2) the rest of the long half (third stream), */ \
+        /* [n2, B) the short half with its own work cap (second stream); n2 <= wave slots: the long half's jobs all start at once       */ \
+        int n2 = (nenv * h->pipe_long_pct / 100 + 63) & ~63; if (n2 > h->slots) n2 = h->slots & ~63; if (n2 < 64) n2 = 64;     \
+        int n1 = (n2 * h->pipe_mid_pct / 100 + 63) & ~63; if (n1 > n2 || !h->stream3) n1 = n2; if (n1 < 64) n1 = 64;            \
         const int b_short = budget > 0 ? (budget * h->pipe_short_pct / 100 > 64 ? budget * h->pipe_short_pct / 100 : 64) : 0; \
-        hipStream_t s_short = h->pipe_swap ? h->stream : h->stream2, s_long = h->pipe_swap ? h->stream2 : h->stream;   \
         (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0);              \
-        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(nenv - n_long), block, lds, s_short, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, b_short, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, n_long);                                 \
-        hipLaunchKernelGGL(wrsn_obs_kernel, dim3(nenv - n_long), dim3(256), h->lds_obs, s_short, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, n_long); \
-        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(n_long), block, lds, s_long, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
-                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0);                                       \
-        if (timed && !h->pipe_swap) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); } \
-        hipLaunchKernelGGL(wrsn_obs_kernel, dim3(n_long), dim3(256), h->lds_obs, s_long, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, 0); \
+        if (n1 < n2) (void)hipStreamWaitEvent(h->stream3, h->ev_fork, 0);                                              \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(nenv - n2), block, lds, h->stream2, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                           auto_reset, b_short, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, n2);                                     \
+        hipLaunchKernelGGL(wrsn_obs_kernel, dim3(nenv - n2), dim3(256), h->lds_obs, h->stream2, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, n2); \
         (void)hipEventRecord(h->ev_join, h->stream2);                                                                 \
+        if (n1 < n2) {                                                                                                 \
+            hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(n2 - n1), block, lds, h->stream3, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                               auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, n1);                                  \
+            hipLaunchKernelGGL(wrsn_obs_kernel, dim3(n2 - n1), dim3(256), h->lds_obs, h->stream3, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, n1); \
+            (void)hipEventRecord(h->ev_join3, h->stream3);                                                             \
+        }                                                                                                              \
+        hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), dim3(n1), block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
+                           auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0);                                       \
+        if (timed) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); }            \
+        hipLaunchKernelGGL(wrsn_obs_kernel, dim3(n1), dim3(256), h->lds_obs, h->stream, h->dev, (const int32_t*)h->dev.render_agent, obs_pipe, h->obs_reuse, (const int32_t*)h->dev.order, 0); \
         (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);                                                            \
-        if (timed && h->pipe_swap) { (void)hipEventRecord(h->ev[2], h->stream); (void)hipEventRecord(h->ev[3], h->stream); } \
+        if (n1 < n2) (void)hipStreamWaitEvent(h->stream, h->ev_join3, 0);                                              \
     }                                                                                                                  \
     else hipLaunchKernelGGL((wrsn_step_kernel<NPL_, WRSN_KERNEL_INLINE>), grid, block, lds, h->stream, (const WrsnDev*)h->d_dev, reset_call, agent_id, action, \
                             auto_reset, budget, epoch, (h->slots & 0xFFFF) | taper, mask, out, 0, dl, 0)
@@ -293,7 +301,7 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
     wrsn_handle* h = new wrsn_handle();
     h->cfg = *cfg; h->stream = nullptr; h->scenario_set = 0; h->step_budget = 0; h->deadline_ticks = 0; h->epoch = 1; h->obs_reuse = 0; h->timing = 0; h->ev_ok = 0; h->ev_obs = 0; h->ev_rec = 0;
     { const char* e = std::getenv("WRSN_PIPE"); h->pipe = (e && *e == '0') ? 0 : 1; }
-    { const char* e = std::getenv("WRSN_PIPE_SWAP"); h->pipe_swap = (e && *e == '1') ? 1 : 0; }
+    { const char* e = std::getenv("WRSN_PIPE_MID_PCT"); h->pipe_mid_pct = e ? std::atoi(e) : 100; if (h->pipe_mid_pct < 10 || h->pipe_mid_pct > 100) h->pipe_mid_pct = 100; }
     { const char* e = std::getenv("WRSN_PIPE_SHORT_PCT"); h->pipe_short_pct = e ? std::atoi(e) : 40; if (h->pipe_short_pct < 5 || h->pipe_short_pct > 100) h->pipe_short_pct = 40; }
     { const char* e = std::getenv("WRSN_PIPE_LONG_PCT"); h->pipe_long_pct = e ? std::atoi(e) : 50; if (h->pipe_long_pct < 10 || h->pipe_long_pct > 90) h->pipe_long_pct = 50; }
     h->stream2 = nullptr; h->ev2_ok = 0; h->cc_bound = 0; h->cus = 256;
@@ -304,6 +312,10 @@ int wrsn_create(const wrsn_cfg* cfg, wrsn_t** out) {
       int lo_p = 0, hi_p = 0;
       if (hi && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess && hi_p != lo_p) se = hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi_p);
       if (se != hipSuccess) se = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking); }
+    h->stream3 = nullptr;
+    if (se == hipSuccess && hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) == hipSuccess) {
+        if (hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(h->stream3); h->stream3 = nullptr; }
+    } else h->stream3 = nullptr;
     if (se == hipSuccess && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess) {
         if (hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess) h->ev2_ok = 1; else (void)hipEventDestroy(h->ev_fork);
     }
@@ -381,6 +393,7 @@ void wrsn_destroy(wrsn_t* h) {
     if (h->ev_ok) for (int i = 0; i < 5; ++i) (void)hipEventDestroy(h->ev[i]);
     if (h->ev2_ok) { (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipEventDestroy(h->ev_join3); (void)hipStreamDestroy(h->stream3); }
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
