@@ -611,34 +611,40 @@ struct Sim {
             SLS()[i] = ((lv + 1) << 1) | al;                   // own entry only
         }
         __syncthreads();
-        // breadth-first levels.  A node found in sweep `cur` gets level cur + 1 in place: a reader of the same sweep
-        // looks for level == cur and is not affected by seeing either the old (-1) or the new value.
+        // breadth-first levels, PUSHED from the frontier (r03; r02 let every node look at its eight neighbours in every sweep: 16 slots x
+        // 8-word LDS gathers per level, 430 K cycles per search at 1 000 nodes with routes of ~60 hops).  A lane keeps the levels of its own
+        // nodes in registers; in sweep `cur` only the slots AT level `cur` read their packed neighbour words and mark every alive, unreached
+        // neighbour with level cur + 1 (several writers, one value); then every lane looks its unreached slots up again.  Neighbourhood is
+        // symmetric (Node.probe_neighbors, Node.py:80-84), so this reaches exactly the nodes the pull form reaches, at the same levels.
+        int lvr[NPL]; unsigned todo = 0;                     // own levels; slots that are alive and unreached
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) { const int ls = SLS()[j * 64 + lane]; lvr[j] = (ls >> 1) - 1; if ((ls & 1) && lvr[j] == -1) todo |= 1u << j; }
         for (int cur = 1; cur <= N; ++cur) {
-            bool ch = false;
+            bool front = false;
 #pragma unroll
-            for (int j0 = 0; j0 < NPL; j0 += kNbGrp) {
-                U4 pk[kNbGrp];
-#pragma unroll
-                for (int q = 0; q < kNbGrp; ++q) pk[q] = snb[(j0 + q) * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < kNbGrp; ++q) {
-                    const int j = j0 + q;
+            for (int j = 0; j < NPL; ++j) {
+                if (lvr[j] == cur) {
+                    front = true;
                     const int i = j * 64 + lane;
-                    const int ls = SLS()[i];
-                    int hit = 0;
+                    const int mark = ((cur + 2) << 1) | 1;
                     if (!((nbr.ovf >> j) & 1u)) {
+                        const U4 pk = snb[i];
                         int idx[8], l2[8];
-                        const unsigned ok = unpack8(pk[q].x, pk[q].y, pk[q].z, pk[q].w, i, idx);
+                        const unsigned ok = unpack8(pk.x, pk.y, pk.z, pk.w, i, idx);
                         wrsn_lds_gather8_b32(SLS(), idx, l2);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) hit |= (int)((ok >> k) & 1u) & l2[k] & (int)(((l2[k] >> 1) - 1) == cur);
-                    } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { const int l2 = SLS()[nb]; hit |= l2 & (int)(((l2 >> 1) - 1) == cur); })
-                    if ((ls & 1) && (ls >> 1) == 0 && (hit & 1)) { SLS()[i] = ((cur + 2) << 1) | 1; ch = true; }   // alive, level == -1
+                        for (int k = 0; k < 8; ++k) if (((ok >> k) & 1u) && (l2[k] & 1) && (l2[k] >> 1) == 0) SLS()[idx[k]] = mark;
+                    } else WRSN_FOR_NEIGHBORS_CSR(i, nb, { const int l2 = SLS()[nb]; if ((l2 & 1) && (l2 >> 1) == 0) SLS()[nb] = mark; })
                 }
             }
+            if (!wv_any(front)) break;
             __syncthreads();
-            if (!wv_any(ch)) break;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                if ((todo >> j) & 1u) { const int l2 = SLS()[j * 64 + lane]; if ((l2 >> 1) != 0) { lvr[j] = (l2 >> 1) - 1; todo &= ~(1u << j); } }
+            }
         }
+        __syncthreads();
         }
         bool changed = false;
 #pragma unroll
