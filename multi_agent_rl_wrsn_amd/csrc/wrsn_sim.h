@@ -320,12 +320,11 @@ struct Sim {
     WDEV double WRSN_GLOBAL_AS* RING() const { return wrsn_global((use_snap ? dp->snap.ring : dp->live.ring) + (size_t)env * WRSN_RING * NP); }
     WDEV double WRSN_GLOBAL_AS* LOGBUF() const { return wrsn_global((use_snap ? dp->snap.logbuf : dp->live.logbuf) + (size_t)env * NP); }
     // ---- LDS carve-up (must match wrsn_lds_bytes)
-    WDEV double* SRR() const { return smem_; }
-    WDEV double* SU() const { return smem_ + NP; }
-    WDEV int32_t* SLS() const { return (int32_t*)(smem_ + 3 * NP); }
+    WDEV double* SU() const { return smem_; }
+    WDEV int32_t* SLS() const { return (int32_t*)(smem_ + 2 * NP); }
     WDEV int32_t* SRCV() const { return SLS() + NP; }
     // time-parallel steady batch: float CS per node, records / per-second table of the (few) nodes being charged
-    WDEV float* SCSF() const { return (float*)(smem_ + 4 * NP); }
+    WDEV float* SCSF() const { return (float*)(smem_ + 3 * NP); }
     WDEV double* SCHGREC() const { return (double*)SCSF() + NP / 2; }                    // [CHG_MAX][8]: E, d1, d2, rr, node, E_final, CS
     WDEV double* SCHGTAB() const { return SCHGREC() + 8 * kChgMax; }                 // [CHG_MAX][64] energy at the reward instant of second s
     WDEV WrsnAgent* SAG() const { return (WrsnAgent*)(SCHGTAB() + 64 * kChgMax); }
@@ -335,16 +334,52 @@ struct Sim {
     WDEV double* SCONNXY() const { return (double*)(SCS() + (M + 1)); }                 // [M][CC][2] position of every connected node
     WDEV double* SURRATE() const { return SCONNXY() + 2 * M * CC; }
     WDEV double* SURACC() const { return SURRATE() + M * CC; }
-    WDEV double* SREQD() const { return SURACC() + M * CC; }                            // [0] time limit, [1] now, [2] seq (as int64), [3] spare
+    // Node.energyRR (Node.py:31, 137-146) as a SPARSE list of the nodes whose charging rate is not zero: at most a few nodes are inside the
+    // charging range of a charger at a time (r02 kept a float64 per node in LDS: 8 KB at 1 024 nodes, the difference between three and four
+    // environments per CU there)
+    WDEV int RRCAP() const { return M * CC + 32; }
+    WDEV double* SRRV() const { return SURACC() + M * CC; }                             // [RRCAP] rates
+    WDEV double* SREQD() const { return SRRV() + RRCAP(); }                             // [0] time limit, [1] now, [2] seq (as int64), [3] spare
     WDEV Scalar* SS() const { return (Scalar*)(SREQD() + 4); }
     WDEV int32_t* SREQ() const { return (int32_t*)(EC() + 1); }                           // [0] request, [1] argument, [2] live connections, [3] flags
     WDEV int32_t* SCA() const { return SREQ() + 4; }
     WDEV int32_t* SCTR() const { return SCA() + (M + 1); }
     WDEV int32_t* SCP() const { return SCTR() + (M + 1); }
     WDEV int32_t* SURN() const { return SCP() + (M + 1); }
-    WDEV int16_t* SCONN() const { return (int16_t*)(SURN() + 1); }
+    WDEV int32_t* SRRN() const { return SURN() + 1; }                                   // entries of the charging-rate list
+    WDEV int16_t* SCONN() const { return (int16_t*)(SRRN() + 1); }
     WDEV int16_t* SURIDX() const { return SCONN() + M * CC; }
     WDEV int16_t* SURAGENT() const { return SURIDX() + M * CC; }
+    WDEV int16_t* SRRI() const { return SURAGENT() + M * CC; }                          // [RRCAP] nodes of the charging-rate list
+
+    // energyRR of node i += delta (lane 0; the same float64 additions, in the same order, as on a per-node array)
+    WDEV void rr_add(int i, double delta) {
+        int n = SRRN()[0];
+        for (int k = 0; k < n; ++k) {
+            if (SRRI()[k] == i) {
+                const double v = SRRV()[k] + delta;
+                if (v == 0.0) { --n; SRRI()[k] = SRRI()[n]; SRRV()[k] = SRRV()[n]; SRRN()[0] = n; } else SRRV()[k] = v;
+                return;
+            }
+        }
+        if (delta == 0.0) return;
+        if (n >= RRCAP()) { err = -11; return; }
+        SRRI()[n] = (int16_t)i; SRRV()[n] = delta; SRRN()[0] = n + 1;
+    }
+    // scale * energyRR of the lane's nodes
+    WDEV void rr_slots(double (&out)[NPL], double scale) const {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) out[j] = 0.0;
+        const int n = SRRN()[0];
+        for (int k = 0; k < n; ++k) {
+            const int i = SRRI()[k]; const double v = SRRV()[k] * scale;
+            if ((i & 63) == lane) {
+                const int jj = i >> 6;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) out[j] = (j == jj) ? v : out[j];
+            }
+        }
+    }
 
     // -------------------------------------------------------------- setup
     WDEV void bind(const WrsnDev* dp_, int env_, int lane_, double* smem) {
@@ -490,7 +525,6 @@ struct Sim {
         for (int j = 0; j < NPL; ++j) {
             const int i = j * 64 + lane; const bool real = i < N;
             E[j] = real ? E[j] : 0.0; CS[j] = real ? CS[j] : 0.0; d1[j] = real ? d1[j] : 0.0; d2[j] = real ? d2[j] : 0.0;
-            SRR()[i] = real ? rr[j] : 0.0;
             const int ls = real ? lsw[j] : 0; SLS()[i] = ls;
             SRCV()[i] = real ? rcw[j] : -1;
             am |= (unsigned)(ls & 1) << j;
@@ -503,6 +537,19 @@ struct Sim {
 #pragma unroll
         for (int k = 0; k < kCnT; ++k) { const int w = lane + 64 * k; if (w < ncn) { SCONN()[w] = vc[k]; SCONNXY()[2 * w] = vx[k]; SCONNXY()[2 * w + 1] = vy[k]; } }
         for (int w = lane; w <= M; w += 64) { SCTR()[w] = 0; SCP()[w] = 0; SCA()[w] = 0; SCT()[w] = 0; SCS()[w] = 0; }
+        {   // the charging-rate list: the nodes whose energyRR in HBM is not zero
+            int base = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int i = j * 64 + lane; const bool nz = i < N && rr[j] != 0.0;
+                const unsigned long long mk = __ballot(nz);
+                const int pos = base + __popcll(mk & ((1ull << lane) - 1ull));
+                if (nz && pos < RRCAP()) { SRRI()[pos] = (int16_t)i; SRRV()[pos] = rr[j]; }
+                base += __popcll(mk);
+            }
+            if (base > RRCAP()) { err = -11; base = RRCAP(); }
+            if (lane == 0) SRRN()[0] = base;
+        }
         if (lane == 0) { SREQ()[0] = 0; SREQ()[1] = 0; SREQ()[2] = n_conn0; SS()->n_events = n_ev0; SURN()[0] = 0; }
         __syncthreads();
         WRSN_PROF_ADD(10)
@@ -513,11 +560,12 @@ struct Sim {
         const size_t nb = (size_t)env * NP;
         const auto gE = wrsn_global(a.E + nb), gCS = wrsn_global(a.CS + nb), gd1 = wrsn_global(a.d1 + nb), gd2 = wrsn_global(a.d2 + nb), gRR = wrsn_global(a.RR + nb);
         const auto gls = wrsn_global(a.ls + nb), grcv = wrsn_global(a.rcv + nb);
+        double rrv[NPL]; rr_slots(rrv, 1.0);
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
             int i = j * 64 + lane;
             if (i < N) {                                   // arrays nothing touched since load() are not written back
-                gE[i] = E[j]; gRR[i] = SRR()[i];
+                gE[i] = E[j]; gRR[i] = rrv[j];
                 if (dirty & 4) gCS[i] = CS[j];
                 if (dirty & 1) {
                     gd1[i] = d1[j]; gd2[i] = d2[j];
@@ -1425,7 +1473,8 @@ struct Sim {
         const bool any_rr = SREQ()[2] > 0;
         double rrh[NPL];
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) rrh[j] = any_rr ? SRR()[j * 64 + lane] * 0.5 : 0.0;
+        for (int j = 0; j < NPL; ++j) rrh[j] = 0.0;
+        if (any_rr) rr_slots(rrh, 0.5);
         for (long guard = 0; guard < 4000000L; ++guard) {
             WRSN_PROF_MARK(lh0_)
             if (frozen) break;
@@ -1659,7 +1708,7 @@ struct Sim {
             int i = SCONN()[a * CC + k];
             if (!(SLS()[i] & 1)) continue;
             double r = conn_rate_of(a, k, i);
-            SRR()[i] += sign * r; cr += sign * r; cnt++;
+            rr_add(i, sign * r); cr += sign * r; cnt++;
         }
         SAG()[a].charging_rate = cr;
         if (sign > 0) { SAG()[a].n_live = cnt; SREQ()[2] += cnt; }
@@ -2086,7 +2135,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
         bool real = i < s.N;
         s.E[j] = real ? ec->capacity : 0.0; s.CS[j] = 0.0; s.d1[j] = 0.0; s.d2[j] = 0.0;
         int al = (real && ec->capacity > ec->threshold) ? 1 : 0;
-        s.SRR()[i] = 0.0; s.SLS()[i] = al; s.SRCV()[i] = -1;
+        s.SLS()[i] = al; s.SRCV()[i] = -1;
         s.am |= (unsigned)al << j;
     }
     s.now = 0.0; s.seq = 0; s.last_minfit = 0.0; s.opmax = 0.0;
@@ -2101,7 +2150,7 @@ __global__ void __launch_bounds__(64, WRSN_WAVES_PER_SIMD(NPL)) wrsn_warmup_kern
     for (int w = lane; w <= s.M; w += 64) { s.SCTR()[w] = 0; s.SCP()[w] = 0; s.SCA()[w] = 0; s.SCT()[w] = 0; s.SCS()[w] = 0; }
     __syncthreads();
     if (lane == 0) {
-        s.SREQ()[0] = 0; s.SREQ()[1] = 0; s.SREQ()[2] = 0; s.SURN()[0] = 0;
+        s.SREQ()[0] = 0; s.SREQ()[1] = 0; s.SREQ()[2] = 0; s.SURN()[0] = 0; s.SRRN()[0] = 0;
         for (int m = 0; m < s.M; ++m) {                      // MobileCharger.__init__ + WRSN.py:44-49
             s.SAG()[m].loc[0] = ec->bs[0]; s.SAG()[m].loc[1] = ec->bs[1]; s.SAG()[m].energy = ec->mc_capacity; s.SAG()[m].charging_rate = 0.0;
             s.SAG()[m].status = 1; s.mc_check_status(m);

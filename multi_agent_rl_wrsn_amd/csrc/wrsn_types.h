@@ -136,7 +136,8 @@ struct WrsnStepOutDev {
 // LDS of one environment wave; must match the carve-up of Sim (wrsn_sim.h)
 static inline int wrsn_lds_bytes(int NP, int M, int CC) {
     int b = 0;
-    b += 3 * NP * 8 + 2 * NP * 4;                     // charging rate, 2 scratch arrays, level/alive words, cached receivers
+    b += 2 * NP * 8 + 2 * NP * 4;                     // 2 scratch arrays, level/alive words, cached receivers
+    b += (M * CC + 32) * (8 + 2) + 4;                 // the charging rates (Node.energyRR) as a sparse list: rates, nodes, count
     b += M * (int)sizeof(WrsnAgent) + 2 * M * (int)sizeof(WrsnThread);
     b += (M + 1) * (8 + 8);                           // condition times / seqs
     b += 4 * M * CC * 8;                              // connected-node positions (x, y), reward-entry rates and accumulators
