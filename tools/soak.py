@@ -5,7 +5,8 @@ sys.path.insert(0, ROOT)
 import torch
 from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
 B = int(os.environ.get("WRSN_B", "4096")); K = int(os.environ.get("WRSN_K", "3000")); budget = int(os.environ.get("WRSN_BUDGET", "1250"))
-env = VecWRSN([synth_scenario(7000 + e, 200, 200) for e in range(B)], None, 3, auto_reset=True, step_budget=budget, step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")), reuse_obs=True)
+NN = int(os.environ.get("WRSN_N", "200")); MM = int(os.environ.get("WRSN_M", "3"))
+env = VecWRSN([synth_scenario(7000 + e, NN, NN) for e in range(B)], None, MM, auto_reset=True, step_budget=budget, step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")), reuse_obs=True)
 g = torch.Generator(device="cuda").manual_seed(11)
 r = env.reset()
 bad = torch.zeros((), dtype=torch.int64, device="cuda"); nan = torch.zeros((), dtype=torch.int64, device="cuda")
@@ -20,6 +21,6 @@ for k in range(K):
         torch.cuda.synchronize(); print("launch %d: negative status %d, non-finite %d, longest in-flight run %d launches, %.1f s" % (k + 1, int(bad), int(nan), int(worst), time.time() - t0), flush=True)
 torch.cuda.synchronize()
 c = env.counters(); tab = env.rollout_table().cpu()
-print("env-steps %d, episodes %d, mean lifetime %.1f s, obs finite %s" % (c["env_steps"], int(tab[:, 3].sum()), float(tab[:, 4].sum() / max(1.0, float(tab[:, 3].sum()))), bool(torch.isfinite(r["state"]).all())))
+print("env-steps %d, episodes %d, mean lifetime %.1f s, obs finite %s" % (c["env_steps"], int(tab[:, MM].sum()), float(tab[:, MM + 1].sum() / max(1.0, float(tab[:, MM].sum()))), bool(torch.isfinite(r["state"]).all())))
 assert int(bad) == 0 and int(nan) == 0
 print("soak ok")
