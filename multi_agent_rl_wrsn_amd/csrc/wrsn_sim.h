@@ -76,6 +76,9 @@
 // visit costs a load and a store whatever it achieves); a packet-exact second (~70 us) is not begun less than WRSN_EXACT_MARGIN before it,
 // unless it is the first item of the visit (every environment a launch takes advances)
 #ifndef WRSN_PULL_MARGIN
+#ifndef WRSN_NBREG_MAX
+#define WRSN_NBREG_MAX 6          // up to this many node slots per lane the packed neighbour ids stay in registers during a sweep
+#endif
 #define WRSN_PULL_MARGIN 3000
 #endif
 #ifndef WRSN_TICKS_PER_FUSED_SECOND
@@ -404,7 +407,7 @@ struct Sim {
     // node are packed 16 bit each (0xFFFF = none) next to the send cost of that hop; nodes with more neighbours walk the
     // sorted CSR lists instead.  A routine that sweeps the graph loads these once (independent 16-byte loads) and then only
     // touches LDS; with NPL > 6 the ids would not fit the register file and every sweep re-reads the (L2-resident) table.
-    static constexpr bool kNbReg = (NPL <= 6);
+    static constexpr bool kNbReg = (NPL <= WRSN_NBREG_MAX);
     struct NbRegs { uint32_t p[kNbReg ? NPL : 1][4]; unsigned ovf, direct; int ncov[NPL]; };
     WDEV void load_neighbors(NbRegs& nb) const {
         nb.ovf = 0; nb.direct = 0;
