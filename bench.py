@@ -108,10 +108,11 @@ def measure(torch, dist, dev, scenarios, M, G, rank, seed, budget, steps, warmup
     # ---- a timed region of K steps that lasts less than min_seconds is too short for samplers around the run (the driver passes
     #      --steps 20: ~12 ms): a second region of as many steps as min_seconds needs is timed the same way and reported beside it
     res["ext"] = None
-    if min_seconds > 0 and elapsed < min_seconds:
-        k2 = int(min(100000, max(steps + 1, steps * min_seconds / max(elapsed, 1e-6) * 1.2)))
-        if dist:                                               # every rank runs the same number of extra steps
-            kt_ = torch.tensor([k2], dtype=torch.int64, device=dev); dist.all_reduce(kt_, op=dist.ReduceOp.MAX); k2 = int(kt_[0])
+    el_all = elapsed
+    if dist and min_seconds > 0:                               # one decision for the whole job (the ranks' clocks differ by microseconds:
+        et_ = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(et_, op=dist.ReduceOp.MAX); el_all = float(et_[0])   # a rank alone in a collective would hang)
+    if min_seconds > 0 and el_all < min_seconds:
+        k2 = int(min(100000, max(steps + 1, steps * min_seconds / max(el_all, 1e-6) * 1.2)))
         torch.cuda.synchronize(dev)
         if dist:
             dist.barrier()
