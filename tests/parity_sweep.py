@@ -11,11 +11,12 @@ from wrsn_oracle import OracleWRSN
 from parity import close
 
 
-def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
+def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True, M=None, deadline_us=None):
     """returns (requests compared, finished episodes, noise-dependent requests); raises AssertionError on a mismatch"""
-    M = int(os.environ.get("WRSN_M", "3"))
+    M = int(os.environ.get("WRSN_M", "3")) if M is None else M
+    deadline_us = int(os.environ.get("WRSN_DEADLINE_US", "0")) if deadline_us is None else deadline_us
     scs = [synth_scenario(seed0 + e, N, N) for e in range(B)]
-    env = VecWRSN(scs, None, M, step_budget=budget, step_deadline_us=int(os.environ.get("WRSN_DEADLINE_US", "0")))
+    env = VecWRSN(scs, None, M, step_budget=budget, step_deadline_us=deadline_us)
     ors = [OracleWRSN(s.node_xy, s.target_xy, s.bs_xy, s.node_spec, DEFAULT_MC_SPEC, s.max_time, M) for s in scs]
     r = env.reset(); env.synchronize()
     last = [o.reset() for o in ors]
@@ -98,7 +99,7 @@ def run(B=192, K=60, budget=0, seed0=20000, N=200, verbose=True):
                 err = np.max(np.abs(o - ref)) / max(1.0, np.abs(ref).max()); worst_obs = max(worst_obs, err)
                 assert err <= 1e-5, ("obs", step, e, err)
         busy = st == 4
-        if step % 10 == 9:
+        if verbose and step % 10 == 9:
             print("step %d: %d requests compared (%d noise-dependent), %d episodes finished, worst reward rel err %.2e, worst obs err %.2e, %.0f s" % (step + 1, n_cmp, n_noise, n_term, worst_rew, worst_obs, time.time() - t0), flush=True)
     print("parity sweep ok: %d requests, %d finished episodes; %d requests with a reward that depends on the sign of a rounding-noise energyCS (not comparable)" % (n_cmp, n_term, n_noise))
     env.close(); pool.shutdown()

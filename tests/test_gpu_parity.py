@@ -451,6 +451,23 @@ def test_parity_sweep_whole_episodes_with_resets(budget):
     assert n_cmp > 600 and n_term > 80 and n_noise < n_cmp // 50
 
 
+@pytest.mark.parametrize("case", ["pipeline_budget_512x200", "pipeline_blocking_512x200", "time_sliced_192x200", "budget_48x1000_8mc", "budget_96x200_8mc"])
+def test_parity_sweep_wide(case):
+    """The sweep at the sizes the launch machinery switches on (r03: the builder-run sweeps of r02 in the suite): 512 environments --
+    the two-stage pipeline of a step call, with the default work budget and with blocking steps --, time-sliced launches, 1 000 nodes x 8
+    chargers (16 node slots per lane, pushed level search, sparse charging-rate list) and 8 chargers on 200 nodes (overlapping
+    charging ranges).  Every request of every launch against the oracle, whole episodes with resets."""
+    _torch()
+    import parity_sweep
+    kw = {"pipeline_budget_512x200": dict(B=512, K=40, budget=1250, seed0=61000),
+          "pipeline_blocking_512x200": dict(B=512, K=24, budget=0, seed0=62000),
+          "time_sliced_192x200": dict(B=192, K=40, budget=0, seed0=63000, deadline_us=150),
+          "budget_48x1000_8mc": dict(B=48, K=40, budget=1250, seed0=64000, N=1000, M=8),
+          "budget_96x200_8mc": dict(B=96, K=40, budget=1250, seed0=65000, N=200, M=8)}[case]
+    n_cmp, n_term, n_noise = parity_sweep.run(verbose=False, **kw)
+    assert n_cmp > 1000 and n_term > 50 and n_noise <= max(2, n_cmp // 200)
+
+
 def _write_yaml(tmp_path, z):
     import yaml
     from multi_agent_rl_wrsn_amd.scenario import MC_SPEC_KEYS, NODE_SPEC_KEYS
