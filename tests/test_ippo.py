@@ -1,5 +1,6 @@
 """f2 / f4 on the CPU: policy networks and trainer arithmetic against vectors generated from the reference's own modules
-(tests/golden_policy/policy_nets.npz, script oracle/refharness/gen_policy_golden.py), the batch selection, the device-side
+(tests/golden_policy/policy_nets.npz, script oracle/refharness/gen_policy_golden.py), the PPO update against the reference's own update
+loop run on its own networks (tests/golden_policy/update_step.npz, oracle/refharness/gen_update_golden.py), the batch selection, the device-side
 transition bookkeeping (emulated kernels) against the reference's list bookkeeping restated from controller/ippo/IPPO.py:137-155,
 and the data-parallel gradient exchange on a world-2 gloo group."""
 import os
@@ -45,6 +46,48 @@ def test_networks_match_the_reference_modules():
     assert np.allclose(mean.numpy(), z["actor_mean"], rtol=1e-4, atol=1e-5)
     assert np.allclose(log_std.detach().numpy(), z["actor_log_std"], rtol=0, atol=1e-7)
     assert np.allclose(value.numpy(), z["critic_value"], rtol=1e-4, atol=1e-6)
+
+
+def _update_batch(torch, B, G):
+    """the batch of oracle/refharness/gen_update_golden.py (closed formulas of the element index)"""
+    i = torch.arange(B * 4 * G * G, dtype=torch.float64)
+    states = (0.5 + 0.5 * torch.sin(0.0131 * i + 0.7)).reshape(B, 4, G, G)
+    states[:, 0] *= 3.0
+    j = torch.arange(B * G * G, dtype=torch.float64)
+    k = torch.arange(B, dtype=torch.float64)
+    return dict(states=states.float(), actions=(0.3 * torch.sin(0.0173 * j + 0.2)).reshape(B, G, G).float(), advantages=torch.cos(1.3 * k + 0.1).float(),
+                returns=(0.5 * torch.sin(0.7 * k) + 0.2).float(), values=(0.4 * torch.sin(0.7 * k + 0.3)).float())
+
+
+@pytest.mark.parametrize("case", ["split", "whole"])
+def test_update_matches_the_reference_update_loop(case):
+    """f4 pinned (r03): `PPOLearner.update` against what the reference's OWN update loop (the `for` node of IPPO.train, IPPO.py:230-271,
+    with its `evaluate` / `get_value`, executed by oracle/refharness/gen_update_golden.py on the reference's networks) leaves behind:
+    the loss of every minibatch step, the clip fractions, and every parameter and BatchNorm buffer after the update.  `split`: 16 rows
+    in shuffled minibatches of 8, every ratio clipped (what a roll-out really leaves); `whole`: the unclipped policy gradient."""
+    import torch
+    from multi_agent_rl_wrsn_amd import PPOLearner
+    z = np.load(os.path.join(ROOT, "tests", "golden_policy", "update_step.npz"))
+    G, seed = (int(v) for v in z["shape"]); B, MB, EPOCHS = (int(v) for v in z[case + "_shape"])
+    torch.manual_seed(0); torch.set_num_threads(4)
+    lr = PPOLearner({"lr": 3.0e-4, "clip": 0.2, "batch_size": B, "minibatch_size": MB, "n_updates_per_iteration": EPOCHS, "norm_adv": True,
+                     "clip_vloss": True, "ent_coef": 0.0, "vf_coef": 0.5, "max_grad_norm": 0.5}, 1, G, "cpu")
+    formula_fill(lr.actors[0]); formula_fill(lr.critics[0])
+    batch = _update_batch(torch, B, G); batch["log_probs"] = torch.from_numpy(z[case + "_log_probs"])
+    np.random.seed(seed)
+    stats = lr.update(0, batch)
+    losses = np.array(lr.loggers[0]["losses"])
+    assert losses.shape == z[case + "_losses"].shape and np.allclose(losses, z[case + "_losses"], rtol=2e-4, atol=1e-6), (losses, z[case + "_losses"])
+    assert abs(stats[4] - float(np.mean(z[case + "_clipfracs"]))) < 1e-6
+    for tag, net in (("actor", lr.actors[0]), ("critic", lr.critics[0])):
+        sd = {n: t for n, t in net.state_dict().items() if t.dtype.is_floating_point}
+        assert list(sd) == list(z[case + "_" + tag + "_names"])
+        for (name, t), ref in zip(sd.items(), z[case + "_" + tag + "_stats"]):
+            f = t.detach().double().flatten()
+            got = np.array([float(f.sum()), float(f.abs().sum())] + [float(v) for v in f[:4]] + [0.0] * max(0, 4 - f.numel()))
+            tol = 2e-5 * max(1.0, float(f.abs().sum())) / max(1, f.numel()) ** 0.5 + 1e-6
+            assert np.allclose(got[:2], ref[:2], rtol=0, atol=tol * max(1, f.numel()) ** 0.5), (tag, name, got, ref)
+            assert np.allclose(got[2:], ref[2:], rtol=1e-4, atol=2e-6), (tag, name, got, ref)
 
 
 def test_cal_rt_adv_matches_the_reference_function():
