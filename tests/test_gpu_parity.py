@@ -852,14 +852,15 @@ def test_rollouts_continue_the_episodes_instead_of_restarting_them():
     env.close()
 
 
-def test_pipelined_step_calls_return_what_single_launches_return(monkeypatch):
+@pytest.mark.parametrize("B,K,budgets", [(1024, 30, (1250, 0)), (777, 12, (1250,)), (513, 12, (0,))])
+def test_pipelined_step_calls_return_what_single_launches_return(monkeypatch, B, K, budgets):
     """A step call that renders is issued as a two-stage pipeline over the launch order (wrsn_api.hip: the short half is stepped and
     rendered on a second stream while the long half is stepped; the short half's work cap is 40 % of the budget).  Per environment the
     requests -- agent, time, terminal, reward, observation -- are those of the single launch (WRSN_PIPE=0); only the call a request is
-    reported in may differ (another cap for a step in the short half).  Budgeted and blocking, 1 024 environments, whole episodes."""
+    reported in may differ (another cap for a step in the short half).  Budgeted and blocking, 1 024 environments, whole episodes; and batch
+    sizes that are no multiple of the wavefront / of the stage granularity (777, 513: the launch order is padded to a power of two)."""
     torch = _torch()
     from multi_agent_rl_wrsn_amd import VecWRSN, synth_scenario
-    B, K = 1024, 30
     uniq = [synth_scenario(15000 + u, 200, 200) for u in range(B)]
     g = torch.Generator().manual_seed(9)
     acts = torch.rand((K, B, 3), generator=g, dtype=torch.float64)
@@ -884,7 +885,7 @@ def test_pipelined_step_calls_return_what_single_launches_return(monkeypatch):
                     hist[e].append((int(st[e]), int(a[e]), float(now[e]), float(rew[e]), int(term[e]), float(osum[e]) if a[e] >= 0 else 0.0))
         env.close()
         return hist
-    for budget in (1250, 0):
+    for budget in budgets:
         h0 = run(False, budget); h1 = run(True, budget)
         n_cmp = 0
         for e in range(B):
@@ -894,4 +895,4 @@ def test_pipelined_step_calls_return_what_single_launches_return(monkeypatch):
                 assert q0[:3] == q1[:3] and q0[4] == q1[4], (budget, e, q0, q1)
                 assert abs(q0[3] - q1[3]) <= 1e-7 * max(1.0, abs(q0[3])) and abs(q0[5] - q1[5]) <= 1e-6 * max(1.0, abs(q0[5])), (budget, e, q0, q1)
             n_cmp += n
-        assert n_cmp > 20000
+        assert n_cmp > 0.6 * B * K
