@@ -66,6 +66,9 @@ struct WrsnEnvDyn {
     int32_t fit_dirty, map1_valid;           // node state changed (a grid service ran) since last_minfit was evaluated / since map 1 of the
     uint64_t map1_ptr;                       // observation was rendered into the row at this address (wrsn_set_obs_reuse; written by the observation kernel)
     int32_t n_connected, error, log_pending, susp;   // susp: WRSN.step in flight (work budget of a launch used up)
+    // error (0 = none; the row reports status WRSN_ERR_CAPACITY and the code stays readable through wrsn_peek): -6 event loop guard, -7 no
+    // event and no grid item, -8 no free process record, -9 connection list longer than its bound, -10 service loop ran out, -11 charging-rate
+    // list full (more than M * CC + 32 nodes with a non-zero energyRR)
     // work-queue launches (wrsn_set_step_deadline): the action of a WRSN.step call that no wave has taken up yet (wrsn_latch_kernel); the
     // environment may wait for its turn over several launches, during which the caller's row says "in flight" and is ignored
     int32_t lat_valid, lat_agent; double lat_action[3];
