@@ -156,6 +156,42 @@ def reference_bookkeeping(step, reset, n_agent, n_decisions):
     return out
 
 
+def test_bookkeeping_restatement_and_selection_match_the_reference_roll_out():
+    """f2 pinned (r03): the reference's OWN `roll_out` (IPPO.py:119-210, run by oracle/refharness/gen_rollout_golden.py on the scripted
+    environment of tests/script_env.py) against `reference_bookkeeping` above -- the restatement the device-side transition buffers are
+    held to -- and against `select_batch`: the stored (state, reward, next state) lists the reference hands `cal_rt_adv` per episode and
+    charger, and the batches it returns after its reward-outlier selection (states, actions, log-probabilities, rewards, next states, and
+    the positions its returns / advantages / values were taken from)."""
+    from multi_agent_rl_wrsn_amd import select_batch
+    from script_env import ScriptEnv, scripted_policy
+    z = np.load(os.path.join(ROOT, "tests", "golden_policy", "rollout_bookkeeping.npz"))
+    n_agent, batch, env_seed, sel_seed = (int(v) for v in z["shape"]); n_dec = int(z["n_decisions"])
+    env = ScriptEnv(env_seed, n_agent)
+
+    def wrap(r):
+        r = dict(r); r["policy"] = lambda n, a=r["agent_id"]: scripted_policy(n, a); return r
+    per_agent = reference_bookkeeping(lambda a, action: wrap(env.step(a, action)), lambda: wrap(env.reset()), n_agent, n_dec)
+    # the lists cal_rt_adv received, call by call (one call per episode and charger with stored transitions), and a tag per stored transition
+    want = [dict(states=[], rewards=[], next_states=[], tags=[]) for _ in range(n_agent)]
+    for c in range(int(z["n_calls"])):
+        a = int(z["call_agent"][c]); w = want[a]
+        w["states"] += list(z["call%d_states" % c]); w["rewards"] += list(z["call%d_rewards" % c]); w["next_states"] += list(z["call%d_next_states" % c])
+        w["tags"] += [(c, q) for q in range(len(z["call%d_rewards" % c]))]
+        assert not z["call%d_terminals" % c].any()              # stored transitions are never terminal (IPPO.py:144-145)
+    np.random.seed(sel_seed)
+    for a in range(n_agent):
+        got = per_agent[a]; w = want[a]
+        assert len(got) == len(w["rewards"]) >= batch
+        assert np.array_equal(np.array([t[0] for t in got]), np.array(w["states"])) and np.array_equal(np.array([t[4] for t in got]), np.array(w["next_states"]))
+        assert np.array_equal(np.array([t[3] for t in got], dtype=np.float32), np.array(w["rewards"], dtype=np.float32))
+        idx = select_batch([t[3] for t in got], batch)          # the selections of the chargers draw from one stream, in charger order
+        assert np.array_equal(z["batch_states_%d" % a], np.array([got[i][0] for i in idx])) and np.array_equal(z["batch_next_states_%d" % a], np.array([got[i][4] for i in idx]))
+        assert np.array_equal(z["batch_actions_%d" % a], np.array([got[i][1] for i in idx])) and np.array_equal(z["batch_log_probs_%d" % a], np.array([got[i][2] for i in idx], dtype=np.float32))
+        assert np.array_equal(z["batch_rewards_%d" % a], np.array([got[i][3] for i in idx], dtype=np.float32))
+        for name, k in (("returns", 1000.0), ("advantages", 2000.0), ("values", 3000.0)):      # the tagged values the stand-in cal_rt_adv returned
+            assert np.array_equal(z["batch_%s_%d" % (name, a)], np.array([k * w["tags"][i][0] + w["tags"][i][1] for i in idx], dtype=np.float32)), (name, a)
+
+
 def test_emulated_transition_buffers_equal_the_reference_bookkeeping():
     """wrsn_rollout_record / wrsn_rollout_collect (csrc/wrsn_rollout.h, emulated) over a batch with auto-reset and a step
     budget == the reference's per-environment list bookkeeping on single environments."""
